@@ -1,0 +1,115 @@
+#!/usr/bin/env python3
+"""Regenerates tests/golden/* from the COMPILED REFERENCE (oracle/_ref/libagmv_ref.so).
+
+Run in the build container only (needs /root/reference for agmv_splash.agmv and to build
+oracle/_ref):   python tests/golden/make_golden.py
+
+What is committed is DATA: inputs are regenerated deterministically by tests/synth.py, the
+expected outputs come from the reference's own compiled functions.
+"""
+import hashlib
+import json
+import os
+import shutil
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+import oracles as O  # noqa: E402
+import synth as S  # noqa: E402
+
+REFROOT = "/root/reference"
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def encode_clip(W, H, T, mode512, first_frame_count=0):
+    frames = [S.synth_frame(W, H, t) for t in range(T)]
+    p0, p1 = S.content_palettes(frames[:4])
+    enc = O.RefEncoder(W, H, mode512, p0, p1, first_frame_count)
+    outs, ents = [], []
+    for f in frames:
+        b, e = enc.encode(f, True)
+        outs.append(b)
+        ents.append(e)
+    enc.close()
+    return frames, p0, p1, outs, ents
+
+
+def main():
+    O.build_oracles()
+    assert O.have_ref(), "reference build missing"
+    meta = {}
+
+    # ---- 1. nearest-entry known answers (E2/E3) ------------------------------------
+    rng = np.random.default_rng(20241008)
+    p0, p1 = S.random_palettes(11)
+    p1[:16] = p0[:16]                       # cross-palette ties -> palette0 must win
+    p0[40:44] = p0[40]                      # in-palette ties -> lowest index must win
+    pix = rng.integers(0, 1 << 24, size=8192, dtype=np.uint32)
+    pix[:256] = p0
+    pix[256:512] = p1
+    pix[512:520] |= np.uint32(0xAB000000)   # bits >= 24 are ignored
+    e512 = np.zeros(len(pix), np.uint16)
+    e256 = np.zeros(len(pix), np.uint16)
+    O.ref().refshim_nearest_entries(p0, p1, 1, pix, len(pix), e512)
+    O.ref().refshim_nearest_entries(p0, p1, 0, pix, len(pix), e256)
+    np.savez_compressed(os.path.join(HERE, "nearest.npz"), p0=p0, p1=p1, pix=pix, e512=e512, e256=e256)
+
+    # ---- 2. tiny clip with complete bitstreams (E4-E9), both colour modes ----------
+    for mode512 in (1, 0):
+        W, H, T = 64, 48, 9
+        frames, p0, p1, outs, ents = encode_clip(W, H, T, mode512)
+        np.savez_compressed(
+            os.path.join(HERE, "clip64x48_m%d.npz" % (512 if mode512 else 256)),
+            p0=p0, p1=p1, sizes=np.array([len(o) for o in outs], np.uint32),
+            bytes=np.concatenate(outs), entries0=ents[0], entries1=ents[1])
+
+    # ---- 3. larger clips: hashes only ------------------------------------------------
+    for (W, H, T) in ((320, 240, 8), (1280, 720, 4)):
+        for mode512 in (1, 0):
+            frames, p0, p1, outs, ents = encode_clip(W, H, T, mode512)
+            meta["clip%dx%d_m%d" % (W, H, 512 if mode512 else 256)] = {
+                "W": W, "H": H, "T": T, "p0_sha": sha(p0), "p1_sha": sha(p1),
+                "usize": [int(len(o)) for o in outs], "bytes_sha": [sha(o) for o in outs],
+                "entries_sha": [sha(e) for e in ents]}
+
+    # ---- 4. decode of the reference's own sample file (config 1) ----------------------
+    src = os.path.join(REFROOT, "agmv_splash.agmv")
+    shutil.copyfile(src, os.path.join(HERE, "agmv_splash.agmv"))
+    os.chmod(os.path.join(HERE, "agmv_splash.agmv"), 0o644)
+    err, info, fr = O.ref_decode_file(src)
+    assert err == 0
+    meta["agmv_splash"] = {
+        "file_sha": hashlib.sha256(open(src, "rb").read()).hexdigest(),
+        "w": info[0], "h": info[1], "n": info[2], "version": info[3],
+        "usize": [f["usize"] for f in fr], "csize": [f["csize"] for f in fr],
+        "bpos": [f["bpos"] for f in fr], "pix_sha": [sha(f["pix"]) for f in fr]}
+    # header-rejection fixture: first 2 KiB of the old-layout file is enough for the header
+    with open(os.path.join(REFROOT, "agmv_spash.agmv"), "rb") as f:
+        open(os.path.join(HERE, "agmv_spash_header.bin"), "wb").write(f.read(2048))
+
+    # ---- 5. LZ stage known answers (N1) ----------------------------------------------
+    import ctypes as C
+    frames, p0, p1, outs, ents = encode_clip(320, 240, 2, 1)
+    lz = {}
+    for k, o in enumerate(outs):
+        xin = np.concatenate([o, np.zeros(8, np.uint8)])
+        for comp, name in ((1, "lzss"), (2, "lz77")):
+            out = np.zeros(4 * len(o) + 64, np.uint8)
+            cs = C.c_uint32()
+            n = O.ref().refshim_lz(xin, len(o), comp, out, len(out), C.byref(cs))
+            lz["%s_%d" % (name, k)] = {"n_in": int(len(o)), "in_sha": sha(o), "n_out": int(n),
+                                       "csize": int(cs.value), "out_sha": sha(out[:n])}
+    meta["lz_320x240"] = lz
+
+    json.dump(meta, open(os.path.join(HERE, "golden.json"), "w"), indent=1, sort_keys=True)
+    print("golden written:", sorted(os.listdir(HERE)))
+
+
+if __name__ == "__main__":
+    main()
