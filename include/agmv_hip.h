@@ -1,0 +1,135 @@
+/*
+ * include/agmv_hip.h -- the C-ABI drop-in boundary of the MI355X hot path.
+ *
+ * libagmv has no plugin/FFI layer: consumers call its C API directly
+ * (reference include/agmv_encode.h:26-37, include/agmv_decode.h:21-26).  The
+ * per-frame functions of that API are FILE*-coupled, one frame per call, and
+ * take LP64 `unsigned long` pixels (8 B/px, reference include/agmv_defines.h:22)
+ * -- a shape no GPU can be fed through.  This header therefore declares the
+ * batch entry points that the reference-compatible host layer (include/agmv.h,
+ * libagmv_amd/csrc/agmv_api.c) is built on, and that a maintainer of the
+ * reference would bind.  Plain pointers and sizes only.
+ *
+ * Conventions
+ *   pixel   4-byte 0x00RRGGBB (bits >= 24 ignored, reference src/agmv_utils.c:632-642)
+ *   frame   w*h pixels, row-major, w and h multiples of 4 (reference src/agmv_encode.c:365-366)
+ *   entry   u16 = pal_num << 8 | index   (GPU form of AGMV_ENTRY, include/agmv_defines.h:122-126)
+ *   d_*     device pointers (HIP), h_* host pointers; `stream` is a hipStream_t (NULL = default)
+ *   return  0 on success, negative on error (agmv_hip_last_error() gives the text).
+ *           There is NO CPU fallback: without a usable GPU every entry point fails.
+ */
+#ifndef AGMV_HIP_H
+#define AGMV_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct agmv_hip_ctx agmv_hip_ctx;
+
+/* bytes a frame's pre-LZ bitstream can take at most: 33 (512-colour) or 17 (256-colour)
+   bytes per 4x4 block (reference src/agmv_encode.c:381-403 / :420-431), rounded up to 256.
+   NOTE the reference's own buffer (w*h*2, src/agmv_utils.c:338) is too small for the
+   512-colour worst case. */
+size_t agmv_hip_max_usize(uint32_t w, uint32_t h, int mode512);
+
+int          agmv_hip_device_count(void);
+agmv_hip_ctx* agmv_hip_create(int device);
+void         agmv_hip_destroy(agmv_hip_ctx* ctx);
+const char*  agmv_hip_last_error(void);
+
+/* -- palette ------------------------------------------------------------------------------
+ * Replaces the per-pixel 256/512-way search of AGMV_FindNearestColor / AGMV_FindNearestEntry
+ * (reference src/agmv_utils.c:785-816, :851-895) by an exact 2^24-entry table built ONCE per
+ * palette on the GPU with the same argmin and the same tie rules (lowest index inside a
+ * palette, palette0 on cross-palette ties).  Also builds the 512x512 "within +-2 per channel"
+ * bit matrix used by the block tests (reference src/agmv_encode.c:293, :345).
+ * mode512: 1 = two palettes (OPT_I/III/GBA_I/GBA_III/NDS, container v1/v3),
+ *          0 = palette0 only (OPT_II/ANIM/GBA_II, container v2/v4). */
+int agmv_hip_set_palette(agmv_hip_ctx* ctx, const uint32_t p0[256], const uint32_t p1[256],
+                         int mode512, void* stream);
+
+/* exact nearest entries for n pixels (loop A of AGMV_EncodeFrame, src/agmv_encode.c:556-558 /
+   :589-592) -- exposed for parity tests of the table. */
+int agmv_hip_quantise_dev(agmv_hip_ctx* ctx, const uint32_t* d_pix, size_t n, uint16_t* d_entries,
+                          void* stream);
+
+/* -- encode -------------------------------------------------------------------------------
+ * Loops A+B of AGMV_EncodeFrame for n_frames consecutive frames (reference
+ * src/agmv_encode.c:552-565 / :589-599, :626-630): quantise, I/P block classification
+ * (CompareIFrameBlock :302-352, ComparePFrameBlock :240-300), byte assembly
+ * (AssembleIFrameBitstream :354-436, AssemblePFrameBitstream :438-527).
+ * Frame f of the batch has frame_count = first_frame_count + f; it is an I-frame when
+ * frame_count % 4 == 0.  d_out receives frame f's pre-LZ bitstream at d_out + f*out_stride
+ * (out_stride >= agmv_hip_max_usize), d_sizes[f] its length (`usize`).
+ * d_iframe_entries (w*h u16, may be NULL): if the batch starts inside a GOP
+ * (first_frame_count % 4 != 0) it supplies the entries of that GOP's I-frame
+ * (agmv->iframe_entries); on return it holds the entries of the last I-frame of the batch. */
+int agmv_hip_encode_frames_dev(agmv_hip_ctx* ctx, const uint32_t* d_pix, uint32_t n_frames,
+                               uint32_t w, uint32_t h, uint32_t first_frame_count,
+                               uint8_t* d_out, size_t out_stride, uint32_t* d_sizes,
+                               uint16_t* d_iframe_entries, void* stream);
+/* same from/to host memory (does the H2D/D2H itself, synchronous) */
+int agmv_hip_encode_frames(agmv_hip_ctx* ctx, const uint32_t* h_pix, uint32_t n_frames,
+                           uint32_t w, uint32_t h, uint32_t first_frame_count,
+                           uint8_t* h_out, size_t out_stride, uint32_t* h_sizes,
+                           uint16_t* h_iframe_entries);
+
+/* -- decode -------------------------------------------------------------------------------
+ * The parse + reconstruct half of AGMV_DecodeFrameChunk (reference src/agmv_decode.c:224-407)
+ * for n_frames consecutive frames whose LZ stage (:171-222, host) has already run.
+ *   d_bits + f*bits_stride : frame f's decompressed bitstream; bytes [bpos, bpos+16) must hold
+ *                            what the reference's persistent buffer holds there (stale bytes of
+ *                            earlier frames, or 0) -- they are read on over-run.
+ *   d_bpos[f]              : bitstream->pos after the LZ stage (may differ from usize).
+ * agmv_hip_parse_frames_dev computes, per frame, the byte position at which each 4x4 block is
+ * entered (d_offsets[f*nblk + k]) and how many blocks are entered before the reference raises
+ * `escape` (d_nentered[f]).  agmv_hip_decode_frames_dev turns that into pixels:
+ * d_pix_out + f*w*h.  d_prev_frame / d_prev_iframe (w*h pixels, may be NULL = zeroed, the state
+ * of a fresh decoder) are img_data / iframe->img_data before the first frame of the batch;
+ * blocks the bitstream does not reach keep the previous frame's pixels (:229-232). */
+int agmv_hip_parse_frames_dev(agmv_hip_ctx* ctx, const uint8_t* d_bits, size_t bits_stride,
+                              const uint32_t* d_bpos, uint32_t n_frames, uint32_t w, uint32_t h,
+                              uint32_t* d_offsets, uint32_t* d_nentered, void* stream);
+int agmv_hip_decode_frames_dev(agmv_hip_ctx* ctx, const uint8_t* d_bits, size_t bits_stride,
+                               const uint32_t* d_bpos, const uint32_t* d_offsets,
+                               const uint32_t* d_nentered, uint32_t n_frames, uint32_t w,
+                               uint32_t h, uint32_t first_frame_count, uint32_t* d_pix_out,
+                               const uint32_t* d_prev_frame, const uint32_t* d_prev_iframe,
+                               void* stream);
+/* host-memory convenience: parse on the GPU, reconstruct, copy back (synchronous) */
+int agmv_hip_decode_frames(agmv_hip_ctx* ctx, const uint8_t* h_bits, size_t bits_stride,
+                           const uint32_t* h_bpos, uint32_t n_frames, uint32_t w, uint32_t h,
+                           uint32_t first_frame_count, uint32_t* h_pix_out,
+                           const uint32_t* h_prev_frame, const uint32_t* h_prev_iframe);
+
+/* -- helpers on the caller side of the path -------------------------------------------------*/
+/* canonical synthetic clip agmv_synth_v1: frames t0..t0+n-1 into d_pix */
+int agmv_hip_synth_dev(agmv_hip_ctx* ctx, uint32_t* d_pix, uint32_t w, uint32_t h, uint32_t t0,
+                       uint32_t n_frames, uint64_t seed, void* stream);
+/* PDIFS midpoint frame, AGMV_InterpFrame (reference src/agmv_utils.c:949-969) */
+int agmv_hip_interp_dev(agmv_hip_ctx* ctx, uint32_t* d_out, const uint32_t* d_f1,
+                        const uint32_t* d_f2, size_t n_pixels, void* stream);
+/* pass-1 colour histogram of the palette build: hist[AGMV_QuantizeColor(px, quality)] += 1
+   (reference src/agmv_encode.c:2390-2394, src/agmv_utils.c:695-742); hist has 2^19 bins */
+int agmv_hip_histogram_dev(agmv_hip_ctx* ctx, const uint32_t* d_pix, size_t n_pixels, int quality,
+                           uint32_t* d_hist, void* stream);
+
+/* check for an asynchronous device-side failure (look-back timeout) after synchronising */
+int agmv_hip_check(agmv_hip_ctx* ctx, void* stream);
+
+/* raw device memory for C hosts that do not link the HIP runtime themselves */
+void* agmv_hip_malloc(size_t bytes);
+void  agmv_hip_free(void* d);
+int   agmv_hip_memcpy_h2d(void* d, const void* h, size_t bytes);
+int   agmv_hip_memcpy_d2h(void* h, const void* d, size_t bytes);
+int   agmv_hip_memset(void* d, int value, size_t bytes);
+int   agmv_hip_sync(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

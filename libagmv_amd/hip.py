@@ -1,0 +1,220 @@
+"""ctypes binding of include/agmv_hip.h.
+
+The product is the shared library; this module only marshals pointers.  torch is used for
+device memory and streams (plumbing).  Every failure is loud: a missing library raises
+HipUnavailable at load time, a failing call raises RuntimeError with the library's message.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+# every symbol include/agmv_hip.h declares (tests check the built library exports them all)
+ABI_SYMBOLS = [
+    "agmv_hip_max_usize", "agmv_hip_device_count", "agmv_hip_create", "agmv_hip_destroy",
+    "agmv_hip_last_error", "agmv_hip_set_palette", "agmv_hip_quantise_dev",
+    "agmv_hip_encode_frames_dev", "agmv_hip_encode_frames", "agmv_hip_parse_frames_dev",
+    "agmv_hip_decode_frames_dev", "agmv_hip_decode_frames", "agmv_hip_synth_dev",
+    "agmv_hip_interp_dev", "agmv_hip_histogram_dev", "agmv_hip_check", "agmv_hip_malloc",
+    "agmv_hip_free", "agmv_hip_memcpy_h2d", "agmv_hip_memcpy_d2h", "agmv_hip_memset",
+    "agmv_hip_sync",
+]
+
+
+class HipUnavailable(RuntimeError):
+    pass
+
+
+def lib_path():
+    return os.path.join(HERE, "libagmv_hip.so")
+
+
+_lib = None
+
+
+def load_library():
+    """dlopen libagmv_hip.so (built in-tree by libagmv_amd/build.py). No fallback."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    p = lib_path()
+    if not os.path.exists(p):
+        raise HipUnavailable("%s is missing: run `python -m libagmv_amd.build` (or "
+                             "__graft_entry__.build()); the AGMV hot path has no CPU fallback" % p)
+    try:
+        L = C.CDLL(p)
+    except OSError as e:
+        raise HipUnavailable("cannot load %s: %s" % (p, e))
+    vp, sz, u32 = C.c_void_p, C.c_size_t, C.c_uint32
+    L.agmv_hip_max_usize.restype = sz
+    L.agmv_hip_max_usize.argtypes = [u32, u32, C.c_int]
+    L.agmv_hip_device_count.restype = C.c_int
+    L.agmv_hip_create.restype = vp
+    L.agmv_hip_create.argtypes = [C.c_int]
+    L.agmv_hip_destroy.argtypes = [vp]
+    L.agmv_hip_last_error.restype = C.c_char_p
+    L.agmv_hip_set_palette.argtypes = [vp, vp, vp, C.c_int, vp]
+    L.agmv_hip_quantise_dev.argtypes = [vp, vp, sz, vp, vp]
+    L.agmv_hip_encode_frames_dev.argtypes = [vp, vp, u32, u32, u32, u32, vp, sz, vp, vp, vp]
+    L.agmv_hip_encode_frames.argtypes = [vp, vp, u32, u32, u32, u32, vp, sz, vp, vp]
+    L.agmv_hip_parse_frames_dev.argtypes = [vp, vp, sz, vp, u32, u32, u32, vp, vp, vp]
+    L.agmv_hip_decode_frames_dev.argtypes = [vp, vp, sz, vp, vp, vp, u32, u32, u32, u32, vp, vp, vp, vp]
+    L.agmv_hip_decode_frames.argtypes = [vp, vp, sz, vp, u32, u32, u32, u32, vp, vp, vp]
+    L.agmv_hip_synth_dev.argtypes = [vp, vp, u32, u32, u32, u32, C.c_uint64, vp]
+    L.agmv_hip_interp_dev.argtypes = [vp, vp, vp, vp, sz, vp]
+    L.agmv_hip_histogram_dev.argtypes = [vp, vp, sz, C.c_int, vp, vp]
+    L.agmv_hip_check.argtypes = [vp, vp]
+    L.agmv_hip_malloc.restype = vp
+    L.agmv_hip_malloc.argtypes = [sz]
+    L.agmv_hip_free.argtypes = [vp]
+    for f in (L.agmv_hip_set_palette, L.agmv_hip_quantise_dev, L.agmv_hip_encode_frames_dev,
+              L.agmv_hip_encode_frames, L.agmv_hip_parse_frames_dev, L.agmv_hip_decode_frames_dev,
+              L.agmv_hip_decode_frames, L.agmv_hip_synth_dev, L.agmv_hip_interp_dev,
+              L.agmv_hip_histogram_dev, L.agmv_hip_check):
+        f.restype = C.c_int
+    _lib = L
+    return L
+
+
+def _np_ptr(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+class AgmvHip:
+    """One context = one GPU + one palette.  Device-resident calls take torch CUDA tensors
+    (uint8 / int16 / int32 storage: torch has no unsigned 16/32-bit arithmetic types, the bytes
+    are what matters) and run on torch's current stream."""
+
+    def __init__(self, device=0):
+        self.L = load_library()
+        self.ctx = self.L.agmv_hip_create(int(device))
+        if not self.ctx:
+            raise HipUnavailable(self.L.agmv_hip_last_error().decode())
+        self.device = int(device)
+        self.mode512 = None
+
+    def close(self):
+        if getattr(self, "ctx", None):
+            self.L.agmv_hip_destroy(self.ctx)
+            self.ctx = None
+
+    __del__ = close
+
+    # ------------------------------------------------------------------ helpers
+    def _ck(self, rc):
+        if rc != 0:
+            raise RuntimeError(self.L.agmv_hip_last_error().decode())
+
+    @staticmethod
+    def _stream():
+        import torch
+        return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def max_usize(self, w, h):
+        return self.L.agmv_hip_max_usize(w, h, int(self.mode512))
+
+    def set_palette(self, p0, p1, mode512=True):
+        p0 = np.ascontiguousarray(p0, np.uint32)
+        p1 = np.ascontiguousarray(p1, np.uint32) if p1 is not None else np.zeros(256, np.uint32)
+        self.mode512 = bool(mode512)
+        self._ck(self.L.agmv_hip_set_palette(self.ctx, _np_ptr(p0), _np_ptr(p1), int(mode512), self._stream()))
+
+    def check(self):
+        self._ck(self.L.agmv_hip_check(self.ctx, self._stream()))
+
+    # ------------------------------------------------------------------ device-resident path
+    def quantise_dev(self, pix):
+        import torch
+        out = torch.empty(pix.numel(), dtype=torch.int16, device=pix.device)
+        self._ck(self.L.agmv_hip_quantise_dev(self.ctx, pix.data_ptr(), pix.numel(), out.data_ptr(), self._stream()))
+        return out
+
+    def encode_dev(self, pix, n_frames, w, h, first_frame_count=0, out=None, sizes=None, ientries=None):
+        """pix: int32 CUDA tensor of n_frames*w*h pixels. Returns (out u8 [n, stride], sizes i32 [n])."""
+        import torch
+        stride = self.max_usize(w, h)
+        if out is None:
+            out = torch.empty((n_frames, stride), dtype=torch.uint8, device=pix.device)
+        if sizes is None:
+            sizes = torch.empty(n_frames, dtype=torch.int32, device=pix.device)
+        self._ck(self.L.agmv_hip_encode_frames_dev(
+            self.ctx, pix.data_ptr(), n_frames, w, h, first_frame_count, out.data_ptr(), out.stride(0),
+            sizes.data_ptr(), ientries.data_ptr() if ientries is not None else None, self._stream()))
+        return out, sizes
+
+    def parse_dev(self, bits, bpos, n_frames, w, h, offsets=None, nentered=None):
+        import torch
+        nblk = (w // 4) * (h // 4)
+        if offsets is None:
+            offsets = torch.empty((n_frames, nblk), dtype=torch.int32, device=bits.device)
+        if nentered is None:
+            nentered = torch.empty(n_frames, dtype=torch.int32, device=bits.device)
+        self._ck(self.L.agmv_hip_parse_frames_dev(self.ctx, bits.data_ptr(), bits.stride(0), bpos.data_ptr(),
+                                                  n_frames, w, h, offsets.data_ptr(), nentered.data_ptr(),
+                                                  self._stream()))
+        return offsets, nentered
+
+    def decode_dev(self, bits, bpos, offsets, nentered, n_frames, w, h, first_frame_count=0, out=None,
+                   prev=None, prev_iframe=None):
+        import torch
+        if out is None:
+            out = torch.empty((n_frames, h, w), dtype=torch.int32, device=bits.device)
+        self._ck(self.L.agmv_hip_decode_frames_dev(
+            self.ctx, bits.data_ptr(), bits.stride(0), bpos.data_ptr(), offsets.data_ptr(), nentered.data_ptr(),
+            n_frames, w, h, first_frame_count, out.data_ptr(),
+            prev.data_ptr() if prev is not None else None,
+            prev_iframe.data_ptr() if prev_iframe is not None else None, self._stream()))
+        return out
+
+    def synth_dev(self, w, h, t0, n_frames, seed=0xA6D5, out=None, device=None):
+        import torch
+        if out is None:
+            out = torch.empty((n_frames, h, w), dtype=torch.int32, device=device or ("cuda:%d" % self.device))
+        self._ck(self.L.agmv_hip_synth_dev(self.ctx, out.data_ptr(), w, h, t0, n_frames, seed, self._stream()))
+        return out
+
+    def interp_dev(self, f1, f2):
+        import torch
+        out = torch.empty_like(f1)
+        self._ck(self.L.agmv_hip_interp_dev(self.ctx, out.data_ptr(), f1.data_ptr(), f2.data_ptr(), f1.numel(),
+                                            self._stream()))
+        return out
+
+    def histogram_dev(self, pix, quality=1, hist=None):
+        import torch
+        if hist is None:
+            hist = torch.zeros(1 << 19, dtype=torch.int32, device=pix.device)
+        self._ck(self.L.agmv_hip_histogram_dev(self.ctx, pix.data_ptr(), pix.numel(), quality, hist.data_ptr(),
+                                               self._stream()))
+        return hist
+
+    # ------------------------------------------------------------------ host-buffer path
+    def encode_host(self, frames, first_frame_count=0, ientries=None):
+        """frames: uint32 ndarray [n, h, w]. Returns list of per-frame bitstreams (uint8 arrays)."""
+        frames = np.ascontiguousarray(frames, np.uint32)
+        n, h, w = frames.shape
+        stride = self.max_usize(w, h)
+        out = np.zeros((n, stride), np.uint8)
+        sizes = np.zeros(n, np.uint32)
+        self._ck(self.L.agmv_hip_encode_frames(self.ctx, _np_ptr(frames), n, w, h, first_frame_count,
+                                               _np_ptr(out), stride, _np_ptr(sizes), _np_ptr(ientries)))
+        return [out[i, :sizes[i]].copy() for i in range(n)]
+
+    def decode_host(self, bits_list, w, h, first_frame_count=0, prev=None, prev_iframe=None, pad=None):
+        """bits_list: per-frame decompressed bitstreams. `pad`[f] = the 16 bytes that follow bpos in
+        the reference's persistent buffer (stale bytes), zeros if None."""
+        n = len(bits_list)
+        stride = (max(len(b) for b in bits_list) + 16 + 255) & ~255
+        bits = np.zeros((n, stride), np.uint8)
+        bpos = np.zeros(n, np.uint32)
+        for i, b in enumerate(bits_list):
+            bits[i, :len(b)] = b
+            bpos[i] = len(b)
+            if pad is not None:
+                bits[i, len(b):len(b) + 16] = pad[i]
+        out = np.zeros((n, h, w), np.uint32)
+        self._ck(self.L.agmv_hip_decode_frames(self.ctx, _np_ptr(bits), stride, _np_ptr(bpos), n, w, h,
+                                               first_frame_count, _np_ptr(out), _np_ptr(prev), _np_ptr(prev_iframe)))
+        return out

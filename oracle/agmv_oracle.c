@@ -352,6 +352,13 @@ size_t orc_decoder_lz(orc_decoder* d, const uint8_t* payload, size_t avail, uint
 	return r.pos;
 }
 
+void orc_decoder_set_bitstream(orc_decoder* d, const uint8_t* bytes, uint32_t n)
+{
+	if (n > d->bitstream_cap - 16) n = (uint32_t)(d->bitstream_cap - 16);
+	memcpy(d->bitstream, bytes, n);
+	d->bpos = n;
+}
+
 static inline int is_flag(uint8_t b)
 {
 	return b == ORC_FILL_FLAG || b == ORC_NORMAL_FLAG || b == ORC_COPY_FLAG;

@@ -96,6 +96,9 @@ void orc_decoder_free(orc_decoder* d);
    into the 0xFF guard / next chunk). Returns the number of payload bytes consumed. */
 size_t orc_decoder_lz(orc_decoder* d, const uint8_t* payload, size_t avail, uint32_t usize,
                       uint32_t csize);
+/* test hook: install an already-decompressed bitstream as if the LZ stage had produced it
+   (bytes beyond n keep their stale content, exactly like the reference's persistent buffer) */
+void orc_decoder_set_bitstream(orc_decoder* d, const uint8_t* bytes, uint32_t n);
 /* D2/D3/D4: parse + reconstruct from d->bitstream[0..] with d->bpos, snapshot, frame_count++.
    If entry_offsets != NULL (w*h/16 u32), entry_offsets[k] receives `bitpos` at the moment
    block k is entered (before the flag resync) and *n_entered the number of blocks entered. */

@@ -63,6 +63,8 @@ def oracle():
         L.orc_decoder_free.argtypes = [C.c_void_p]
         L.orc_decoder_lz.restype = C.c_size_t
         L.orc_decoder_lz.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32, C.c_uint32]
+        L.orc_decoder_set_bitstream.restype = None
+        L.orc_decoder_set_bitstream.argtypes = [C.c_void_p, u8p, C.c_uint32]
         L.orc_decoder_parse.restype = None
         L.orc_decoder_parse.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_uint32)]
         L.orc_parse_header.restype = C.c_int
@@ -212,6 +214,36 @@ def oracle_decode_file(data, want_tables=False):
         pos = payload + used
     L.orc_decoder_free(d)
     return 0, info, frames
+
+
+class OracleDecoder:
+    """stateful D2-D4 (restatement) fed with already-decompressed bitstreams."""
+
+    def __init__(self, w, h, mode512, p0, p1):
+        self.L = oracle()
+        self.w, self.h = w, h
+        self.p = self.L.orc_decoder_new(w, h, 1 if mode512 else 2, np.ascontiguousarray(p0, np.uint32),
+                                        np.ascontiguousarray(p1, np.uint32))
+        self.s = C.cast(self.p, C.POINTER(_OrcDecoder)).contents
+
+    def decode(self, bits, want_tables=False):
+        bits = np.ascontiguousarray(bits, np.uint8)
+        self.L.orc_decoder_set_bitstream(self.p, bits, len(bits))
+        padded = np.ctypeslib.as_array(self.s.bitstream, (len(bits) + 16,)).copy()
+        offs = np.zeros(self.w * self.h // 16, np.uint32)
+        n_ent = C.c_uint32(0)
+        self.L.orc_decoder_parse(self.p, offs.ctypes.data_as(C.c_void_p), C.byref(n_ent))
+        pix = np.ctypeslib.as_array(self.s.img, (self.w * self.h,)).copy()
+        if want_tables:
+            return pix, padded, offs, n_ent.value
+        return pix
+
+    def close(self):
+        if self.p:
+            self.L.orc_decoder_free(self.p)
+            self.p = None
+
+    __del__ = close
 
 
 class _OrcDecoder(C.Structure):
