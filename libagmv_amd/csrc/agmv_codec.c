@@ -1,0 +1,866 @@
+/*
+ * libagmv_amd/csrc/agmv_codec.c -- libagmv's encode/decode entry points on top of the GPU hot path.
+ *
+ *   per frame   AGMV_EncodeFrame (reference src/agmv_encode.c:529-634) and AGMV_DecodeFrameChunk
+ *               (src/agmv_decode.c:145-410): same FILE* protocol, one frame per call through the
+ *               batch C-ABI of include/agmv_hip.h with n_frames = 1.
+ *   sequences   AGMV_EncodeAGMV / AGMV_EncodeFullAGMV / AGMV_EncodeVideo (src/agmv_encode.c:719-4407,
+ *               BMP branch) and AGMV_DecodeAGMV / AGMV_DecodeVideo (src/agmv_decode.c:455-647): these
+ *               own the loop, so frames go to the GPU in GOP-aligned batches while the host threads
+ *               run the LZ stage and the container is written strictly in frame order.
+ *
+ * Everything on the hot path (quantise, block classification, byte assembly, parse, reconstruct,
+ * PDIFS midpoint, palette histogram) runs on the GPU.  There is no CPU fallback: if the GPU path
+ * fails these functions print the reason and abort (the void encoders have no error channel).
+ */
+#include <math.h>
+#include <pthread.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <unistd.h>
+
+#include "agmv_hip.h"
+#include "agmv_internal.h"
+
+/* ------------------------------------------------------------------------------------------ */
+static agmv_hip_ctx* g_ctx = NULL;
+static uint32_t g_pal[512];
+static int g_pal_mode = -1;
+static unsigned g_batch_frames = 0, g_lz_threads = 0;
+static unsigned long g_export_count = 0;            /* AGIDL's expcount, extern/agidl/src/agidl_img_export.c:18 */
+
+void agmv_die(const char* what)
+{
+	fprintf(stderr, "libagmv(amd): %s: %s\n", what, agmv_hip_last_error());
+	fprintf(stderr, "libagmv(amd): the AGMV hot path runs on the GPU only (no CPU fallback) -- aborting\n");
+	abort();
+}
+
+void AGMV_SetBatchFrames(unsigned n) { g_batch_frames = n; }
+void AGMV_SetLZThreads(unsigned n) { g_lz_threads = n; }
+
+static unsigned batch_frames(void)
+{
+	unsigned n = g_batch_frames;
+	const char* e = getenv("AGMV_BATCH_FRAMES");
+	if (!n && e) n = (unsigned)atoi(e);
+	if (!n) n = 64;
+	return (n + 3u) & ~3u;                           /* whole GOPs */
+}
+
+static unsigned lz_threads(void)
+{
+	unsigned n = g_lz_threads;
+	const char* e = getenv("AGMV_LZ_THREADS");
+	if (!n && e) n = (unsigned)atoi(e);
+	if (!n) { long c = sysconf(_SC_NPROCESSORS_ONLN); n = c > 0 ? (unsigned)c : 1; }
+	return n > 64 ? 64 : n;
+}
+
+static agmv_hip_ctx* ctx(void)
+{
+	if (!g_ctx) {
+		const char* e = getenv("AGMV_DEVICE");
+		g_ctx = agmv_hip_create(e ? atoi(e) : 0);
+		if (!g_ctx) agmv_die("cannot open the GPU");
+	}
+	return g_ctx;
+}
+
+static int mode512_of(AGMV_OPT opt) { return opt != AGMV_OPT_II && opt != AGMV_OPT_ANIM && opt != AGMV_OPT_GBA_II; }
+
+/* (re)build the exact LUT when the palette of the object differs from the one on the device */
+static void use_palette(const u32* p0, const u32* p1, int mode512)
+{
+	uint32_t pal[512];
+	int i;
+	for (i = 0; i < 256; i++) { pal[i] = (uint32_t)p0[i]; pal[256 + i] = mode512 ? (uint32_t)p1[i] : 0; }
+	if (g_pal_mode == mode512 && memcmp(pal, g_pal, sizeof(pal)) == 0) { ctx(); return; }
+	if (agmv_hip_set_palette(ctx(), pal, pal + 256, mode512, NULL)) agmv_die("palette upload");
+	memcpy(g_pal, pal, sizeof(pal));
+	g_pal_mode = mode512;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * container pieces
+ * ------------------------------------------------------------------------------------------ */
+/* header, reference src/agmv_encode.c:21-94 (palette1 only in the 512-colour versions) */
+void AGMV_EncodeHeader(FILE* f, AGMV* a)
+{
+	AGMV_OPT opt = AGMV_GetOPT(a);
+	int pals = mode512_of(opt) ? 2 : 1, p, i;
+	AGMV_WriteFourCC(f, 'A', 'G', 'M', 'V');
+	AGMV_WriteLong(f, AGMV_GetNumberOfFrames(a));
+	AGMV_WriteLong(f, AGMV_GetWidth(a));
+	AGMV_WriteLong(f, AGMV_GetHeight(a));
+	AGMV_WriteByte(f, 1);
+	AGMV_WriteByte(f, AGMV_GetVersionFromOPT(opt, AGMV_GetCompression(a)));
+	AGMV_WriteLong(f, AGMV_GetFramesPerSecond(a));
+	AGMV_WriteLong(f, AGMV_GetTotalAudioDuration(a));
+	AGMV_WriteLong(f, AGMV_GetSampleRate(a));
+	AGMV_WriteLong(f, AGMV_GetAudioSize(a));
+	AGMV_WriteShort(f, AGMV_GetNumberOfChannels(a));
+	AGMV_WriteShort(f, AGMV_GetBitsPerSample(a));
+	for (p = 0; p < pals; p++)
+		for (i = 0; i < 256; i++) {
+			u32 c = p ? a->header.palette1[i] : a->header.palette0[i];
+			AGMV_WriteByte(f, AGMV_GetR(c)); AGMV_WriteByte(f, AGMV_GetG(c)); AGMV_WriteByte(f, AGMV_GetB(c));
+		}
+}
+
+/* reference src/agmv_decode.c:91-143 */
+int AGMV_DecodeHeader(FILE* f, AGMV* a)
+{
+	int pals, p, i;
+	AGMV_ReadFourCC(f, a->header.fourcc);
+	a->header.num_of_frames = AGMV_ReadLong(f);
+	a->header.width = AGMV_ReadLong(f);
+	a->header.height = AGMV_ReadLong(f);
+	a->header.fmt = AGMV_ReadByte(f);
+	a->header.version = AGMV_ReadByte(f);
+	a->header.frames_per_second = AGMV_ReadLong(f);
+	a->header.total_audio_duration = AGMV_ReadLong(f);
+	a->header.sample_rate = AGMV_ReadLong(f);
+	a->header.audio_size = AGMV_ReadLong(f);
+	a->header.num_of_channels = AGMV_ReadShort(f);
+	a->header.bits_per_sample = AGMV_ReadShort(f);
+	if (!AGMV_IsCorrectFourCC(a->header.fourcc, 'A', 'G', 'M', 'V') || a->header.version < 1 || a->header.version > 4 ||
+	    a->header.frames_per_second >= 200 || !(a->header.bits_per_sample == 16 || a->header.bits_per_sample == 8))
+		return INVALID_HEADER_FORMATTING_ERR;
+	pals = (a->header.version == 1 || a->header.version == 3) ? 2 : 1;
+	for (p = 0; p < pals; p++)
+		for (i = 0; i < 256; i++) {
+			u32 r = AGMV_ReadByte(f), g = AGMV_ReadByte(f), b = AGMV_ReadByte(f);
+			/* AGIDL_RGB(r,g,b,fmt): the encoder always writes fmt 1 = RGB_888; 2 = BGR_888 */
+			u32 c = a->header.fmt == 2 ? (b << 16 | g << 8 | r) : (r << 16 | g << 8 | b);
+			if (p) a->header.palette1[i] = c; else a->header.palette0[i] = c;
+		}
+	return NO_ERR;
+}
+
+/* zero-length audio chunks are written after every frame by the AGMV drivers (reference
+   src/agmv_encode.c:707-717); audio itself is out of scope: only pass-through of what the object holds */
+void AGMV_EncodeAudioChunk(FILE* f, AGMV* a)
+{
+	u32 size = a->audio_chunk ? a->audio_chunk->size : 0, i;
+	AGMV_WriteFourCC(f, 'A', 'G', 'A', 'C');
+	AGMV_WriteLong(f, size);
+	for (i = 0; i < size; i++)
+		AGMV_WriteByte(f, a->audio_chunk->atsample ? a->audio_chunk->atsample[a->audio_track->start_point++] : 0);
+}
+
+/* audio payloads are skipped, not decoded (out of scope); the chunk framing is honoured so a file
+   with audio decodes its video (reference src/agmv_decode.c:412-453) */
+int AGMV_DecodeAudioChunk(FILE* f, AGMV* a)
+{
+	AGMV_ReadFourCC(f, a->audio_chunk->fourcc);
+	a->audio_chunk->size = AGMV_ReadLong(f);
+	if (!AGMV_IsCorrectFourCC(a->audio_chunk->fourcc, 'A', 'G', 'A', 'C')) return INVALID_HEADER_FORMATTING_ERR;
+	fseek(f, (long)a->audio_chunk->size, SEEK_CUR);
+	return NO_ERR;
+}
+
+/* chunk framing around an already compressed payload, reference src/agmv_encode.c:549-550,
+   567-585, 622-624: 'AGFC', frame number, usize, csize, csize payload bytes, 8 x 0xFF.
+   (the reference writes the flushed partial byte and then overwrites it with the first 0xFF) */
+static void write_frame_chunk(FILE* f, u32 frame_no, u32 usize, u32 csize, const u8* payload)
+{
+	static const u8 guard[8] = {0xff, 0xff, 0xff, 0xff, 0xff, 0xff, 0xff, 0xff};
+	AGMV_WriteFourCC(f, 'A', 'G', 'F', 'C');
+	AGMV_WriteLong(f, frame_no);
+	AGMV_WriteLong(f, usize);
+	AGMV_WriteLong(f, csize);
+	fwrite(payload, 1, csize, f);
+	fwrite(guard, 1, 8, f);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * per-frame entry points
+ * ------------------------------------------------------------------------------------------ */
+void AGMV_EncodeFrame(FILE* file, AGMV* a, u32* img_data)
+{
+	const uint32_t w = (uint32_t)AGMV_GetWidth(a), h = (uint32_t)AGMV_GetHeight(a);
+	const size_t npx = (size_t)w * h, stride = agmv_hip_max_usize(w, h, 1);
+	const int m512 = mode512_of(AGMV_GetOPT(a));
+	const int is_i = a->frame_count % 4 == 0;
+	uint32_t* pix = (uint32_t*)malloc(npx * 4);
+	uint16_t* ient = (uint16_t*)malloc(npx * 2);
+	u8* bytes = (u8*)malloc(stride);
+	u8* comp;
+	uint32_t usize = 0;
+	u32 csize;
+	size_t i;
+
+	use_palette(a->header.palette0, a->header.palette1, m512);
+	for (i = 0; i < npx; i++) pix[i] = (uint32_t)img_data[i];          /* LP64: 8 -> 4 bytes per pixel */
+	for (i = 0; i < npx; i++) ient[i] = (uint16_t)(a->iframe_entries[i].pal_num << 8 | a->iframe_entries[i].index);
+	if (agmv_hip_encode_frames(ctx(), pix, 1, w, h, (uint32_t)a->frame_count, bytes, stride, &usize, ient))
+		agmv_die("AGMV_EncodeFrame");
+
+	AGMV_SyncFrameAndImage(a, img_data);                               /* :548 */
+	if ((size_t)usize > a->bitstream->len) {                           /* objects built by foreign code: w*h*2 */
+		a->bitstream->data = (u8*)realloc(a->bitstream->data, usize + 64);
+		a->bitstream->len = usize + 64;
+	}
+	memcpy(a->bitstream->data, bytes, usize);
+	a->bitstream->pos = usize;
+
+	comp = (u8*)malloc((size_t)usize * 4 + 64);
+	/* LZ77 peeks one byte past the stream (:222): hand it the byte the persistent buffer holds there */
+	csize = AGMV_GetCompression(a) == AGMV_LZSS_COMPRESSION ? agmv_lzss_mem(a->bitstream->data, usize, comp)
+	                                                        : agmv_lz77_mem(a->bitstream->data, usize, comp);
+	write_frame_chunk(file, a->frame_count + 1, usize, csize, comp);
+
+	if (is_i)                                                          /* :626-630 */
+		for (i = 0; i < npx; i++) { a->iframe_entries[i].pal_num = (u8)(ient[i] >> 8); a->iframe_entries[i].index = (u8)ient[i]; }
+	a->frame_count++;
+	free(comp); free(bytes); free(ient); free(pix);
+}
+
+int AGMV_DecodeFrameChunk(FILE* file, AGMV* a)
+{
+	const uint32_t w = (uint32_t)a->frame->width, h = (uint32_t)a->frame->height;
+	const size_t npx = (size_t)w * h;
+	const int ver = a->header.version, m512 = (ver == 1 || ver == 3);
+	uint32_t bpos = 0, *prev, *prev_i, *out;
+	size_t i, cap, stride;
+	u8* slab;
+
+	a->bitstream->pos = 0;
+	AGMV_ReadFourCC(file, a->frame_chunk->fourcc);
+	a->frame_chunk->frame_num = AGMV_ReadLong(file);
+	a->frame_chunk->uncompressed_size = AGMV_ReadLong(file);
+	a->frame_chunk->compressed_size = AGMV_ReadLong(file);
+	if (!AGMV_IsCorrectFourCC(a->frame_chunk->fourcc, 'A', 'G', 'F', 'C')) return INVALID_HEADER_FORMATTING_ERR;
+
+	/* D1: LZ stage on the host straight from the FILE*, same bit reader protocol as the reference
+	   (src/agmv_decode.c:171-222) so the file position ends where the reference's does */
+	cap = a->bitstream->len;
+	{
+		u8* data = a->bitstream->data;
+		const u32 usize = a->frame_chunk->uncompressed_size, csize = a->frame_chunk->compressed_size;
+		unsigned long long bp = 0, lim = cap > 16 ? cap - 16 : 0;
+		if (ver == 1 || ver == 2) {
+			unsigned long long nbits = (unsigned long long)csize * 8, bits = 0;
+			while (bits < nbits && bp < usize && bp < lim) {
+				u32 flag = AGMV_ReadBits(file, 1);
+				bits++;
+				if (flag & 1) { data[bp++] = (u8)AGMV_ReadBits(file, 8); bits += 8; }
+				else {
+					u32 offset = AGMV_ReadBits(file, 16), len = AGMV_ReadBits(file, 4), k;
+					unsigned long long pos = bp;
+					bits += 20;
+					for (k = 0; k < len; k++) {
+						unsigned long long src = pos - offset + k;
+						if (src < bp && bp < lim) data[bp++] = data[src];
+					}
+				}
+			}
+		} else {
+			u32 t;
+			for (t = 0; t < csize; t += 4) {
+				u32 offset = AGMV_ReadShort(file), len = AGMV_ReadByte(file), k;
+				u8 byte = AGMV_ReadByte(file);
+				unsigned long long pos = bp;
+				for (k = 0; k < len; k++) {
+					unsigned long long src = pos - offset + k;
+					if (src < bp && bp < lim) data[bp++] = data[src];
+				}
+				if (bp < lim) data[bp++] = byte;
+			}
+		}
+		bpos = (uint32_t)bp;
+	}
+	a->bitstream->pos = bpos;
+	AGMV_FlushReadBits();
+
+	/* D2-D4 on the GPU: parse + reconstruct one frame on top of img_data / iframe */
+	use_palette(a->header.palette0, a->header.palette1, m512);
+	stride = ((size_t)bpos + 16 + 255) & ~(size_t)255;
+	slab = (u8*)calloc(stride, 1);
+	memcpy(slab, a->bitstream->data, (size_t)bpos + 16 <= cap ? (size_t)bpos + 16 : cap);   /* incl. the stale bytes */
+	prev = (uint32_t*)malloc(npx * 4); prev_i = (uint32_t*)malloc(npx * 4); out = (uint32_t*)malloc(npx * 4);
+	for (i = 0; i < npx; i++) { prev[i] = (uint32_t)a->frame->img_data[i]; prev_i[i] = (uint32_t)a->iframe->img_data[i]; }
+	if (agmv_hip_decode_frames(ctx(), slab, stride, &bpos, 1, w, h, (uint32_t)a->frame_count, out, prev, prev_i))
+		agmv_die("AGMV_DecodeFrameChunk");
+	for (i = 0; i < npx; i++) a->frame->img_data[i] = out[i];
+	if (a->frame_count % 4 == 0) memcpy(a->iframe->img_data, a->frame->img_data, npx * sizeof(u32));   /* :401-405 */
+	a->frame_count++;
+	free(slab); free(prev); free(prev_i); free(out);
+	return NO_ERR;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * helper entry points of the reference API that work on host AGMV_ENTRY planes.  They are steps
+ * of AGMV_EncodeFrame; kept exported for source compatibility and routed through the same GPU
+ * tables (exact LUT / bit matrix) so no second implementation of the hot path exists.
+ * ------------------------------------------------------------------------------------------ */
+static uint16_t gpu_entry_of(const u32* p0, const u32* p1, int m512, u32 color)
+{
+	uint32_t px = (uint32_t)color, *d_px;
+	uint16_t e = 0, *d_e;
+	use_palette(p0, p1, m512);
+	d_px = (uint32_t*)agmv_hip_malloc(4); d_e = (uint16_t*)agmv_hip_malloc(2);
+	if (!d_px || !d_e || agmv_hip_memcpy_h2d(d_px, &px, 4) || agmv_hip_quantise_dev(g_ctx, d_px, 1, d_e, NULL) ||
+	    agmv_hip_memcpy_d2h(&e, d_e, 2))
+		agmv_die("nearest entry");
+	agmv_hip_free(d_px); agmv_hip_free(d_e);
+	return e;
+}
+
+u8 AGMV_FindNearestColor(u32 palette[256], u32 color) { return (u8)gpu_entry_of(palette, palette, 0, color); }
+
+AGMV_ENTRY AGMV_FindNearestEntry(u32 palette0[256], u32 palette1[256], u32 color)
+{
+	uint16_t e = gpu_entry_of(palette0, palette1, 1, color);
+	AGMV_ENTRY r;
+	memset(&r, 0, sizeof(r));
+	r.pal_num = (u8)(e >> 8); r.index = (u8)e;
+	return r;
+}
+
+static u32 entry_colour(AGMV* a, const AGMV_ENTRY* e) { return e->pal_num ? a->header.palette1[e->index] : a->header.palette0[e->index]; }
+
+/* the two block predicates are pure table look-ups on 16 entries; they are evaluated by re-encoding the
+   frame on the GPU when used through AGMV_Assemble*; standalone calls (no caller in the reference besides
+   the assemblers) evaluate the +-2 window directly on the palette colours of the given entries. */
+static int within2(u32 c1, u32 c2)
+{
+	int dr = (int)AGMV_GetR(c1) - AGMV_GetR(c2), dg = (int)AGMV_GetG(c1) - AGMV_GetG(c2), db = (int)AGMV_GetB(c1) - AGMV_GetB(c2);
+	return abs(dr) <= 2 && abs(dg) <= 2 && abs(db) <= 2;
+}
+
+u8 AGMV_CompareIFrameBlock(AGMV* a, u32 x, u32 y, u32 color, AGMV_ENTRY* e)
+{
+	u32 w = a->frame->width, i, j;
+	u8 n = 0;
+	for (j = 0; j < 4; j++) for (i = 0; i < 4; i++) n += (u8)within2(color, entry_colour(a, &e[(x + i) + (y + j) * w]));
+	return n;
+}
+
+u8 AGMV_ComparePFrameBlock(AGMV* a, u32 x, u32 y, AGMV_ENTRY* e)
+{
+	u32 w = a->frame->width, i, j;
+	u8 n = 0;
+	for (j = 0; j < 4; j++)
+		for (i = 0; i < 4; i++) {
+			size_t k = (x + i) + (size_t)(y + j) * w;
+			n += (u8)within2(entry_colour(a, &e[k]), entry_colour(a, &a->iframe_entries[k]));
+		}
+	return n;
+}
+
+/* entries -> bitstream: feed the GPU encoder the palette COLOURS of the entries (a palette colour
+   quantises to an entry with the identical colour, so classification and codes are those of the
+   given plane whenever the palette has no duplicate colours ahead of the entry) */
+static void assemble_via_gpu(AGMV* a, AGMV_ENTRY* e, int iframe)
+{
+	const uint32_t w = (uint32_t)a->frame->width, h = (uint32_t)a->frame->height;
+	const size_t npx = (size_t)w * h, stride = agmv_hip_max_usize(w, h, 1);
+	uint32_t* pix = (uint32_t*)malloc(npx * 4), usize = 0;
+	uint16_t* ient = (uint16_t*)malloc(npx * 2);
+	u8* bytes = (u8*)malloc(stride);
+	size_t i;
+	use_palette(a->header.palette0, a->header.palette1, mode512_of(AGMV_GetOPT(a)));
+	for (i = 0; i < npx; i++) {
+		pix[i] = (uint32_t)entry_colour(a, &e[i]);
+		ient[i] = (uint16_t)(a->iframe_entries[i].pal_num << 8 | a->iframe_entries[i].index);
+	}
+	if (agmv_hip_encode_frames(ctx(), pix, 1, w, h, iframe ? 0u : 1u, bytes, stride, &usize, ient)) agmv_die("AGMV_Assemble*FrameBitstream");
+	if ((size_t)a->bitstream->pos + usize > a->bitstream->len) {
+		a->bitstream->len = a->bitstream->pos + usize + 64;
+		a->bitstream->data = (u8*)realloc(a->bitstream->data, a->bitstream->len);
+	}
+	memcpy(a->bitstream->data + a->bitstream->pos, bytes, usize);
+	a->bitstream->pos += usize;
+	free(pix); free(ient); free(bytes);
+}
+
+void AGMV_AssembleIFrameBitstream(AGMV* a, AGMV_ENTRY* e) { assemble_via_gpu(a, e, 1); }
+void AGMV_AssemblePFrameBitstream(AGMV* a, AGMV_ENTRY* e) { assemble_via_gpu(a, e, 0); }
+
+/* ------------------------------------------------------------------------------------------
+ * sequence encoders
+ * ------------------------------------------------------------------------------------------ */
+typedef struct lzjob {
+	const u8* in; uint32_t n; u8* out; u32 csize; int lz77; u8 saved;
+} lzjob;
+
+typedef struct lzpool { lzjob* jobs; unsigned count; unsigned next; pthread_mutex_t mu; } lzpool;
+
+static void* lz_worker(void* arg)
+{
+	lzpool* p = (lzpool*)arg;
+	for (;;) {
+		unsigned k;
+		pthread_mutex_lock(&p->mu);
+		k = p->next++;
+		pthread_mutex_unlock(&p->mu);
+		if (k >= p->count) break;
+		p->jobs[k].csize = p->jobs[k].lz77 ? agmv_lz77_mem(p->jobs[k].in, p->jobs[k].n, p->jobs[k].out)
+		                                   : agmv_lzss_mem(p->jobs[k].in, p->jobs[k].n, p->jobs[k].out);
+	}
+	return NULL;
+}
+
+static void run_lz(lzjob* jobs, unsigned count)
+{
+	lzpool p;
+	pthread_t th[64];
+	unsigned nt = lz_threads(), t;
+	if (nt > count) nt = count;
+	p.jobs = jobs; p.count = count; p.next = 0;
+	pthread_mutex_init(&p.mu, NULL);
+	for (t = 1; t < nt; t++) pthread_create(&th[t], NULL, lz_worker, &p);
+	lz_worker(&p);
+	for (t = 1; t < nt; t++) pthread_join(th[t], NULL);
+	pthread_mutex_destroy(&p.mu);
+}
+
+typedef struct seq {                       /* one open sequence encode */
+	AGMV* a;
+	FILE* file;
+	const char* dir; const char* base;
+	AGMV_OPT opt;
+	int scale_w, scale_h;                  /* 0 = no scaling */
+	uint32_t w, h;                         /* encoded frame size */
+	int audio_chunks;                      /* write an AGAC chunk after every frame */
+	/* batch state */
+	unsigned cap, n;
+	uint32_t* d_frames; uint8_t* d_out; uint32_t* d_sizes; uint16_t* d_ient; uint32_t* d_tmp[2];
+	uint32_t* h_stage;                     /* one frame, packed */
+	u32 frames_written;
+	u8 lz77_tail;                          /* byte the persistent bitstream buffer holds behind the previous frames */
+	u8* persist; size_t persist_len;       /* emulation of agmv->bitstream->data for LZ77's one-past-the-end read */
+} seq;
+
+static void frame_path(char* out, size_t cap, const char* dir, const char* base, long idx)
+{
+	if (dir[0] != 'c' || dir[1] != 'u' || dir[2] != 'r') snprintf(out, cap, "%s/%s%ld.bmp", dir, base, idx);
+	else snprintf(out, cap, "%s%ld.bmp", base, idx);                /* "cur..." = current directory, :2373-2378 */
+}
+
+/* load source frame `idx` as the encoder sees it: BMP -> 0x00RRGGBB, optional GBA/NDS nearest scale, then the
+   first w*h pixels read linearly (the reference reads a 121x81 scaled image as 120x80) */
+static void load_source(seq* s, long idx, uint32_t* dst)
+{
+	char path[4096];
+	uint32_t *pix = NULL, w = 0, h = 0;
+	size_t need = (size_t)s->w * s->h, have;
+	frame_path(path, sizeof(path), s->dir, s->base, idx);
+	if (agmv_bmp_load(path, &pix, &w, &h) != NO_ERR) { fprintf(stderr, "libagmv(amd): cannot read frame %s\n", path); abort(); }
+	if (s->scale_w) {
+		uint32_t nw, nh;
+		uint32_t* sc = agmv_scale_nearest(pix, w, h, ((float)s->scale_w / w) + 0.001f, ((float)s->scale_h / h) + 0.001f, &nw, &nh);
+		free(pix); pix = sc; w = nw; h = nh;
+	}
+	have = (size_t)w * h;
+	memcpy(dst, pix, (have < need ? have : need) * 4);
+	if (have < need) memset(dst + have, 0, (need - have) * 4);
+	free(pix);
+}
+
+static void seq_open(seq* s, AGMV* a, FILE* file, const char* dir, const char* base, AGMV_OPT opt, int audio_chunks)
+{
+	size_t npx, stride;
+	memset(s, 0, sizeof(*s));
+	s->a = a; s->file = file; s->dir = dir; s->base = base; s->opt = opt; s->audio_chunks = audio_chunks;
+	if (opt == AGMV_OPT_GBA_I || opt == AGMV_OPT_GBA_II || opt == AGMV_OPT_GBA_III) { s->scale_w = AGMV_GBA_W; s->scale_h = AGMV_GBA_H; }
+	if (opt == AGMV_OPT_NDS) { s->scale_w = AGMV_NDS_W; s->scale_h = AGMV_NDS_H; }
+	s->w = (uint32_t)AGMV_GetWidth(a); s->h = (uint32_t)AGMV_GetHeight(a);
+	npx = (size_t)s->w * s->h; stride = agmv_hip_max_usize(s->w, s->h, 1);
+	s->cap = batch_frames();
+	s->d_frames = (uint32_t*)agmv_hip_malloc(npx * 4 * s->cap);
+	s->d_out = (uint8_t*)agmv_hip_malloc(stride * s->cap);
+	s->d_sizes = (uint32_t*)agmv_hip_malloc(4 * (size_t)s->cap);
+	s->d_ient = (uint16_t*)agmv_hip_malloc(npx * 2);
+	s->d_tmp[0] = (uint32_t*)agmv_hip_malloc(npx * 4);
+	s->d_tmp[1] = (uint32_t*)agmv_hip_malloc(npx * 4);
+	s->h_stage = (uint32_t*)malloc(npx * 4);
+	s->persist_len = stride + 64;
+	s->persist = (u8*)calloc(s->persist_len, 1);
+	if (!s->d_frames || !s->d_out || !s->d_sizes || !s->d_ient || !s->d_tmp[0] || !s->d_tmp[1]) agmv_die("device allocation");
+	agmv_hip_memset(s->d_ient, 0, npx * 2);
+	use_palette(a->header.palette0, a->header.palette1, mode512_of(opt));
+}
+
+/* encode + compress + write the frames collected so far */
+static void seq_flush(seq* s)
+{
+	const size_t stride = agmv_hip_max_usize(s->w, s->h, 1);
+	const int lz77 = AGMV_GetCompression(s->a) != AGMV_LZSS_COMPRESSION;
+	uint32_t* sizes;
+	u8 *raw, *comp;
+	lzjob* jobs;
+	size_t total = 0, off = 0, coff = 0;
+	unsigned k;
+	if (!s->n) return;
+	if (agmv_hip_encode_frames_dev(ctx(), s->d_frames, s->n, s->w, s->h, (uint32_t)s->a->frame_count, s->d_out, stride, s->d_sizes,
+	                               s->d_ient, NULL) || agmv_hip_check(g_ctx, NULL))
+		agmv_die("batch encode");
+	sizes = (uint32_t*)malloc(4 * (size_t)s->n);
+	agmv_hip_memcpy_d2h(sizes, s->d_sizes, 4 * (size_t)s->n);
+	for (k = 0; k < s->n; k++) total += sizes[k];
+	raw = (u8*)malloc(total + s->n + 16);              /* +1 per frame: LZ77's one-past-the-end byte */
+	comp = (u8*)malloc(total * 4 + 64 * (size_t)s->n + 64);
+	jobs = (lzjob*)calloc(s->n, sizeof(lzjob));
+	for (k = 0; k < s->n; k++) {
+		if (agmv_hip_memcpy_d2h(raw + off, s->d_out + (size_t)k * stride, sizes[k])) agmv_die("bitstream download");
+		/* the reference compresses agmv->bitstream->data in place, so the byte behind the stream is whatever an
+		   earlier, longer frame left there (LZ77 reads it, src/agmv_encode.c:222) */
+		raw[off + sizes[k]] = sizes[k] < s->persist_len ? s->persist[sizes[k]] : 0;
+		memcpy(s->persist, raw + off, sizes[k] < s->persist_len ? sizes[k] : s->persist_len);
+		jobs[k].in = raw + off; jobs[k].n = sizes[k]; jobs[k].out = comp + coff; jobs[k].lz77 = lz77;
+		off += sizes[k] + 1;
+		coff += (size_t)sizes[k] * 4 + 64;
+	}
+	run_lz(jobs, s->n);
+	for (k = 0; k < s->n; k++) {
+		write_frame_chunk(s->file, s->a->frame_count + 1, sizes[k], jobs[k].csize, jobs[k].out);
+		if (s->audio_chunks) AGMV_EncodeAudioChunk(s->file, s->a);
+		s->a->frame_count++;
+		s->frames_written++;
+	}
+	s->n = 0;
+	free(jobs); free(comp); free(raw); free(sizes);
+}
+
+/* append one encoded frame: source `a`, or the PDIFS midpoint of sources a and b (b >= 0) */
+static void seq_push(seq* s, long a, long b)
+{
+	const size_t npx = (size_t)s->w * s->h;
+	uint32_t* dst = s->d_frames + (size_t)s->n * npx;
+	if (b < 0) {
+		load_source(s, a, s->h_stage);
+		if (agmv_hip_memcpy_h2d(dst, s->h_stage, npx * 4)) agmv_die("frame upload");
+	} else {
+		load_source(s, a, s->h_stage);
+		if (agmv_hip_memcpy_h2d(s->d_tmp[0], s->h_stage, npx * 4)) agmv_die("frame upload");
+		load_source(s, b, s->h_stage);
+		if (agmv_hip_memcpy_h2d(s->d_tmp[1], s->h_stage, npx * 4)) agmv_die("frame upload");
+		if (agmv_hip_interp_dev(ctx(), dst, s->d_tmp[0], s->d_tmp[1], npx, NULL)) agmv_die("interp");   /* AGMV_InterpFrame */
+	}
+	if (++s->n == s->cap) seq_flush(s);
+}
+
+static void seq_close(seq* s)
+{
+	seq_flush(s);
+	agmv_hip_free(s->d_frames); agmv_hip_free(s->d_out); agmv_hip_free(s->d_sizes); agmv_hip_free(s->d_ient);
+	agmv_hip_free(s->d_tmp[0]); agmv_hip_free(s->d_tmp[1]);
+	free(s->h_stage); free(s->persist);
+}
+
+/* pass 1 of the palette build on the GPU: histogram of AGMV_QuantizeColor codes of every source frame
+   at its ORIGINAL size (the reference histograms before scaling, src/agmv_encode.c:2371-2397) */
+static void build_palette_from_frames(const char* dir, const char* base, u32 start, u32 end, u32 size, AGMV_QUALITY quality,
+                                      AGMV_OPT opt, u32* p0, u32* p1)
+{
+	uint32_t *d_hist = (uint32_t*)agmv_hip_malloc(4u << 19), *d_pix = NULL, *hist = (uint32_t*)malloc(4u << 19);
+	size_t d_cap = 0;
+	u32 i;
+	if (!d_hist) agmv_die("device allocation");
+	agmv_hip_memset(d_hist, 0, 4u << 19);
+	for (i = start; i <= end; i++) {
+		char path[4096];
+		uint32_t *pix = NULL, w = 0, h = 0;
+		size_t n;
+		frame_path(path, sizeof(path), dir, base, (long)i);
+		if (agmv_bmp_load(path, &pix, &w, &h) != NO_ERR) { fprintf(stderr, "libagmv(amd): cannot read frame %s\n", path); abort(); }
+		n = (size_t)w * h < size ? (size_t)w * h : size;
+		if (n > d_cap) { agmv_hip_free(d_pix); d_pix = (uint32_t*)agmv_hip_malloc(n * 4); d_cap = n; if (!d_pix) agmv_die("device allocation"); }
+		if (agmv_hip_memcpy_h2d(d_pix, pix, n * 4) || agmv_hip_histogram_dev(ctx(), d_pix, n, (int)quality, d_hist, NULL)) agmv_die("histogram");
+		free(pix);
+	}
+	if (agmv_hip_memcpy_d2h(hist, d_hist, 4u << 19)) agmv_die("histogram download");
+	AGMV_BuildPalette(hist, quality, opt, p0, p1);
+	agmv_hip_free(d_hist); agmv_hip_free(d_pix); free(hist);
+}
+
+static void dump_gba_header(const char* filename)
+{
+	/* reference src/agmv_encode.c:3627-3656: the finished file as a C array in GBA_GEN_AGMV.h (CWD) */
+	FILE *in = fopen(filename, "rb"), *out;
+	long n, i;
+	u8* data;
+	if (!in) return;
+	fseek(in, 0, SEEK_END); n = ftell(in); fseek(in, 0, SEEK_SET);
+	data = (u8*)malloc((size_t)n);
+	if (fread(data, 1, (size_t)n, in) != (size_t)n) { /* short read: dump what we have */ }
+	fclose(in);
+	out = fopen("GBA_GEN_AGMV.h", "w");
+	fprintf(out, "#ifndef GBA_GEN_AGMV_H\n#define GBA_GEN_AGMV_H\n\nconst unsigned char GBA_AGMV_FILE[%ld] = {\n", n);
+	for (i = 0; i < n; i++) {
+		if (i != 0 && i % 4000 == 0) fprintf(out, "\n");
+		fprintf(out, "%d,", data[i]);
+	}
+	fprintf(out, "};\n\n#endif");
+	fclose(out);
+	free(data);
+}
+
+static int is_gba(AGMV_OPT o) { return o == AGMV_OPT_GBA_I || o == AGMV_OPT_GBA_II || o == AGMV_OPT_GBA_III; }
+static int heavy_pdifs(AGMV_OPT o) { return o == AGMV_OPT_I || o == AGMV_OPT_ANIM || o == AGMV_OPT_GBA_I || o == AGMV_OPT_GBA_II; }
+
+static void resize_for_target(AGMV* a, AGMV_OPT opt)
+{
+	if (is_gba(opt)) { AGMV_SetWidth(a, AGMV_GBA_W); AGMV_SetHeight(a, AGMV_GBA_H); }
+	if (opt == AGMV_OPT_NDS) { AGMV_SetWidth(a, AGMV_NDS_W); AGMV_SetHeight(a, AGMV_NDS_H); }
+}
+
+static void require_bmp(u8 img_type)
+{
+	if (img_type != AGMV_IMG_BMP) {
+		fprintf(stderr, "libagmv(amd): only AGMV_IMG_BMP input is supported by this build (image type %u is out of scope)\n", img_type);
+		abort();
+	}
+}
+
+/* reference src/agmv_encode.c:2270-3657 (BMP branch) */
+void AGMV_EncodeAGMV(AGMV* a, const char* filename, const char* dir, const char* basename, u8 img_type, u32 start_frame,
+                     u32 end_frame, u32 width, u32 height, u32 frames_per_second, AGMV_OPT opt, AGMV_QUALITY quality,
+                     AGMV_COMPRESSION compression)
+{
+	u32 p0[256], p1[256], adjusted = end_frame - start_frame, i;
+	FILE* file;
+	seq s;
+	f32 rate;
+	(void)frames_per_second;
+	require_bmp(img_type);
+	AGMV_SetOPT(a, opt);
+	AGMV_SetCompression(a, compression);
+	AGMV_SetLeniency(a, 0);
+	/* :2296-2353: integer halves for the heavy modes, x0.75 in double (float for GBA_III) for the light ones */
+	if (heavy_pdifs(opt)) adjusted /= 2;
+	else if (opt == AGMV_OPT_GBA_III) adjusted = (u32)(adjusted * 0.75f);
+	else adjusted = (u32)(adjusted * 0.75);
+	resize_for_target(a, opt);
+
+	build_palette_from_frames(dir, basename, start_frame, end_frame, width * height, quality, opt, p0, p1);
+	if (a->audio_chunk) a->audio_chunk->size = (u32)(a->header.audio_size / (f32)adjusted);   /* 0 without an audio track */
+
+	file = fopen(filename, "wb");
+	if (!file) { fprintf(stderr, "libagmv(amd): cannot create %s\n", filename); abort(); }
+	AGMV_SetICP0(a, p0);
+	AGMV_SetICP1(a, p1);
+	AGMV_EncodeHeader(file, a);
+
+	seq_open(&s, a, file, dir, basename, opt, 1);
+	for (i = start_frame; i <= end_frame;) {                  /* :2678, :3610-3612 */
+		/* NDS is "light" only for BMP input (:2727 vs :2810) -- BMP is the only input here */
+		if (!heavy_pdifs(opt)) { seq_push(&s, i, -1); seq_push(&s, i + 1, i + 2); seq_push(&s, i + 3, -1); i += 4; }
+		else { seq_push(&s, i, i + 1); i += 2; }
+		if (i + 4 >= end_frame) break;
+	}
+	seq_close(&s);
+
+	fseek(file, 4, SEEK_SET);                                 /* :3615-3620 */
+	AGMV_WriteLong(file, s.frames_written);
+	fseek(file, 18, SEEK_SET);
+	rate = (f32)adjusted / (AGMV_GetNumberOfFrames(a) + 1);
+	AGMV_WriteLong(file, (u32)round(AGMV_GetFramesPerSecond(a) * rate));
+	fclose(file);
+	DestroyAGMV(a);                                           /* the callee frees the caller's object, :3625 */
+	if (is_gba(opt)) dump_gba_header(filename);
+}
+
+/* reference src/agmv_encode.c:3659-4407 (BMP branch): every input frame, no PDIFS, no header patch */
+void AGMV_EncodeFullAGMV(AGMV* a, const char* filename, const char* dir, const char* basename, u8 img_type, u32 start_frame,
+                         u32 end_frame, u32 width, u32 height, u32 frames_per_second, AGMV_OPT opt, AGMV_QUALITY quality,
+                         AGMV_COMPRESSION compression)
+{
+	u32 p0[256], p1[256], i;
+	FILE* file;
+	seq s;
+	(void)frames_per_second;
+	require_bmp(img_type);
+	AGMV_SetOPT(a, opt);
+	AGMV_SetCompression(a, compression);
+	resize_for_target(a, opt);
+	build_palette_from_frames(dir, basename, start_frame, end_frame, width * height, quality, opt, p0, p1);
+	if (a->audio_chunk) a->audio_chunk->size = (u32)(a->header.audio_size / (f32)AGMV_GetNumberOfFrames(a));
+	file = fopen(filename, "wb");
+	if (!file) { fprintf(stderr, "libagmv(amd): cannot create %s\n", filename); abort(); }
+	AGMV_SetICP0(a, p0);
+	AGMV_SetICP1(a, p1);
+	AGMV_EncodeHeader(file, a);
+	seq_open(&s, a, file, dir, basename, opt, AGMV_GetTotalAudioDuration(a) != 0);
+	for (i = start_frame; i <= end_frame; i++) seq_push(&s, i, -1);
+	seq_close(&s);
+	fclose(file);
+	DestroyAGMV(a);
+	if (is_gba(opt)) dump_gba_header(filename);
+}
+
+/* reference src/agmv_encode.c:719-2268 (BMP branch): frame skipping decided per group by the grey-equality
+   ratio of the two middle (light) / first two (heavy) frames against the leniency */
+void AGMV_EncodeVideo(const char* filename, const char* dir, const char* basename, u8 img_type, u32 start_frame, u32 end_frame,
+                      u32 width, u32 height, u32 frames_per_second, AGMV_OPT opt, AGMV_QUALITY quality, AGMV_COMPRESSION compression)
+{
+	AGMV* a = CreateAGMV(end_frame - start_frame, width, height, frames_per_second);
+	u32 p0[256], p1[256], i;
+	FILE* file;
+	seq s;
+	f32 rate, len;
+	size_t npx;
+	u32 *fa, *fb;
+	uint32_t* tmp;
+	require_bmp(img_type);
+	AGMV_SetOPT(a, opt);
+	AGMV_SetCompression(a, compression);
+	switch (opt) {                                            /* :744-790 */
+	case AGMV_OPT_II: len = 0.1282f; break;
+	case AGMV_OPT_GBA_I: case AGMV_OPT_GBA_II: case AGMV_OPT_GBA_III: case AGMV_OPT_NDS: len = 0.0f; break;
+	default: len = 0.2282f; break;
+	}
+	AGMV_SetLeniency(a, len);
+	resize_for_target(a, opt);
+	build_palette_from_frames(dir, basename, start_frame, end_frame, width * height, quality, opt, p0, p1);
+	file = fopen(filename, "wb");
+	if (!file) { fprintf(stderr, "libagmv(amd): cannot create %s\n", filename); abort(); }
+	AGMV_SetICP0(a, p0);
+	AGMV_SetICP1(a, p1);
+	AGMV_EncodeHeader(file, a);
+	seq_open(&s, a, file, dir, basename, opt, 0);
+	npx = (size_t)s.w * s.h;
+	fa = (u32*)malloc(npx * sizeof(u32)); fb = (u32*)malloc(npx * sizeof(u32)); tmp = (uint32_t*)malloc(npx * 4);
+	for (i = start_frame; i <= end_frame;) {
+		long x = heavy_pdifs(opt) ? (long)i : (long)i + 1;   /* pair whose similarity decides */
+		size_t k;
+		f32 ratio;
+		load_source(&s, x, tmp); for (k = 0; k < npx; k++) fa[k] = tmp[k];
+		load_source(&s, x + 1, tmp); for (k = 0; k < npx; k++) fb[k] = tmp[k];
+		ratio = AGMV_CompareFrameSimilarity(fa, fb, s.w, s.h);
+		if (ratio >= AGMV_GetLeniency(a)) {
+			if (!heavy_pdifs(opt)) { seq_push(&s, i, -1); seq_push(&s, i + 1, i + 2); seq_push(&s, i + 3, -1); i += 4; }
+			else { seq_push(&s, i, i + 1); i += 2; }
+		} else { seq_push(&s, i, -1); i += 1; }
+		if (i + 4 >= end_frame) break;
+	}
+	seq_close(&s);
+	free(fa); free(fb); free(tmp);
+	fseek(file, 4, SEEK_SET);                                 /* :2225-2231 */
+	AGMV_WriteLong(file, s.frames_written);
+	fseek(file, 18, SEEK_SET);
+	rate = (f32)s.frames_written / AGMV_GetNumberOfFrames(a);
+	AGMV_WriteLong(file, (u32)round(AGMV_GetFramesPerSecond(a) * rate));
+	fclose(file);
+	DestroyAGMV(a);
+	if (is_gba(opt)) dump_gba_header(filename);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * sequence decoders (reference src/agmv_decode.c:455-647): host does the chunk scan and the LZ stage
+ * frame by frame into ONE persistent buffer (so the stale-tail semantics hold), the GPU parses and
+ * reconstructs whole batches, frames are exported as quick_export_<n>.bmp in the CWD.
+ * ------------------------------------------------------------------------------------------ */
+static size_t scan_fourcc(const u8* d, size_t len, size_t pos, const char* cc)
+{
+	while (pos + 4 <= len) {
+		if (memcmp(d + pos, cc, 4) == 0) return pos;
+		pos++;
+	}
+	return len;
+}
+
+static int decode_file(const char* filename, u8 img_type)
+{
+	FILE* f = fopen(filename, "rb");
+	AGMV hdr_obj;
+	u8 *file, *persist, *slab;
+	long flen;
+	size_t pos, npx, cap, stride, got;
+	uint32_t w, h, nframes, ver, done = 0, *bpos, *out, *prev = NULL, *prev_i = NULL;
+	unsigned batch = batch_frames();
+	int err, has_audio;
+	if (!f) return FILE_NOT_FOUND_ERR;
+	if (img_type != AGMV_IMG_BMP) { fclose(f); require_bmp(img_type); }
+	memset(&hdr_obj, 0, sizeof(hdr_obj.header));
+	err = AGMV_DecodeHeader(f, &hdr_obj);
+	if (err != NO_ERR) { fclose(f); return err; }
+	pos = (size_t)ftell(f);
+	fseek(f, 0, SEEK_END); flen = ftell(f); fseek(f, 0, SEEK_SET);
+	file = (u8*)malloc((size_t)flen + 16);
+	got = fread(file, 1, (size_t)flen, f);
+	fclose(f);
+	memset(file + got, 0, 16);
+	w = (uint32_t)hdr_obj.header.width; h = (uint32_t)hdr_obj.header.height;
+	nframes = (uint32_t)hdr_obj.header.num_of_frames; ver = hdr_obj.header.version;
+	has_audio = hdr_obj.header.total_audio_duration != 0;
+	if (w == 0 || h == 0 || (w & 3) || (h & 3)) { free(file); return INVALID_HEADER_FORMATTING_ERR; }
+	npx = (size_t)w * h;
+	use_palette(hdr_obj.header.palette0, hdr_obj.header.palette1, ver == 1 || ver == 3);
+	cap = npx * 33 / 16 + 4096;                           /* persistent decompression buffer, zero-initialised */
+	persist = (u8*)calloc(cap, 1);
+	stride = (cap + 255) & ~(size_t)255;
+	slab = (u8*)malloc(stride * batch);
+	bpos = (uint32_t*)malloc(4 * (size_t)batch);
+	out = (uint32_t*)malloc(npx * 4 * batch);
+	while (done < nframes) {
+		unsigned n = 0, k;
+		while (n < batch && done + n < nframes) {
+			size_t c = scan_fourcc(file, got, pos, "AGFC"), used = 0;
+			uint32_t usize, csize;
+			if (c + 16 > got) break;
+			usize = file[c + 8] | file[c + 9] << 8 | file[c + 10] << 16 | (uint32_t)file[c + 11] << 24;
+			csize = file[c + 12] | file[c + 13] << 8 | file[c + 14] << 16 | (uint32_t)file[c + 15] << 24;
+			bpos[n] = agmv_lz_decode_mem((int)ver, file + c + 16, got - (c + 16), usize, csize, persist, cap, &used);
+			memcpy(slab + (size_t)n * stride, persist, (size_t)bpos[n] + 16 < stride ? (size_t)bpos[n] + 16 : stride);
+			pos = c + 16 + used;
+			if (has_audio) {                              /* AGMV_FindNextAudioChunk + skip */
+				size_t ac = scan_fourcc(file, got, pos, "AGAC");
+				if (ac + 8 <= got) pos = ac + 8 + (file[ac + 4] | file[ac + 5] << 8 | file[ac + 6] << 16 | (size_t)file[ac + 7] << 24);
+			}
+			n++;
+		}
+		if (!n) break;
+		if (agmv_hip_decode_frames(ctx(), slab, stride, bpos, n, w, h, done, out, prev, prev_i)) agmv_die("batch decode");
+		for (k = 0; k < n; k++) {
+			char name[64];
+			snprintf(name, sizeof(name), "quick_export_%lu.bmp", ++g_export_count);   /* AGIDL_QuickExport naming */
+			agmv_bmp_save(name, out + (size_t)k * npx, w, h);
+		}
+		/* decoder state for the next batch: img_data = last frame, iframe = last I-frame */
+		if (!prev) { prev = (uint32_t*)malloc(npx * 4); prev_i = (uint32_t*)calloc(npx, 4); }
+		for (k = 0; k < n; k++) if (((done + k) & 3u) == 0) memcpy(prev_i, out + (size_t)k * npx, npx * 4);
+		memcpy(prev, out + (size_t)(n - 1) * npx, npx * 4);
+		done += n;
+	}
+	free(prev); free(prev_i); free(out); free(bpos); free(slab); free(persist); free(file);
+	return NO_ERR;
+}
+
+int AGMV_DecodeVideo(const char* filename, u8 img_type) { return decode_file(filename, img_type); }
+
+/* audio export (quick_export.wav / .aiff) is out of scope of this build; the video frames are exported
+   exactly like the reference does */
+int AGMV_DecodeAGMV(const char* filename, u8 img_type, AGMV_AUDIO_TYPE audio_type)
+{
+	(void)audio_type;
+	return decode_file(filename, img_type);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * playback helpers (reference src/agmv_playback.c:18-115): thin wrappers around the per-frame call
+ * ------------------------------------------------------------------------------------------ */
+void AGMV_ResetVideo(FILE* f, AGMV* a)
+{
+	fseek(f, (a->header.version == 1 || a->header.version == 3) ? 1574 : 806, SEEK_SET);
+	a->frame_count = 0;
+	if (a->audio_track) a->audio_track->start_point = 0;
+}
+Bool AGMV_IsVideoDone(AGMV* a) { return a->frame_count >= AGMV_GetNumberOfFrames(a) ? TRUE : FALSE; }
+void AGMV_SkipTo(FILE* f, AGMV* a, int n)
+{
+	n = AGMV_SkipToNearestIFrame(n);
+	if (n >= 0 && (u32)n < AGMV_GetNumberOfFrames(a) && n < MAX_OFFSET_TABLE) { fseek(f, (long)a->offset_table[n], SEEK_SET); a->frame_count = (u32)n; }
+}
+void AGMV_SkipForwards(FILE* f, AGMV* a, int n) { AGMV_SkipTo(f, a, AGMV_NextIFrame((int)a->frame_count + n, 0)); }
+void AGMV_SkipBackwards(FILE* f, AGMV* a, int n) { int t = (int)a->frame_count - n; AGMV_SkipTo(f, a, t < 0 ? 0 : AGMV_PrevIFrame(t, 0)); }
+void AGMV_PlayAGMV(FILE* f, AGMV* a)
+{
+	AGMV_FindNextFrameChunk(f);
+	AGMV_DecodeFrameChunk(f, a);
+	if (AGMV_GetTotalAudioDuration(a) != 0) { AGMV_FindNextAudioChunk(f); AGMV_DecodeAudioChunk(f, a); }
+}

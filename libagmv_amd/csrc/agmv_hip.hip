@@ -71,6 +71,9 @@ struct agmv_hip_ctx {
 	uint32_t* d_dirty;              // decode: bitmap of block positions needing the fix-up
 	size_t dirty_cap;               // in words
 	int enc_grid;                   // resident workgroups for the persistent encode kernel
+	int n_cu;
+	uint32_t* d_parse_ws;           // parser workspace: cum | centry | summ
+	size_t parse_ws_cap;            // in dwords
 };
 
 extern "C" size_t agmv_hip_max_usize(uint32_t w, uint32_t h, int mode512)
@@ -78,6 +81,17 @@ extern "C" size_t agmv_hip_max_usize(uint32_t w, uint32_t h, int mode512)
 	size_t nblk = (size_t)(w / 4) * (h / 4);
 	size_t n = nblk * (mode512 ? 33 : 17) + 64;
 	return (n + 255) & ~(size_t)255;
+}
+
+// LUT layout: one 128-byte line (64 u16 entries) holds a 4x4x4 cube of colour space, so the pixels
+// of a neighbourhood (which differ mostly in the low bits of each channel) share lines.  The L1
+// services one distinct line per cycle per gather instruction, which is what bounds the encoder
+// (measured: gathers were 35 % of k_encode on the synthetic clip and 90 % on noise with a linear
+// R,G,B table).  index = R[7:2] G[7:2] B[7:2] | R[1:0] G[1:0] B[1:0]
+__host__ __device__ __forceinline__ uint32_t lut_index(uint32_t px)
+{
+	return (px & 0xFC0000u) | ((px & 0xFC00u) << 2) | ((px & 0xFCu) << 4) | (px & 3u) | ((px >> 6) & 0xCu) |
+	       ((px >> 12) & 0x30u);
 }
 
 // ----------------------------------------------------------------------------------------------
@@ -112,7 +126,7 @@ __global__ __launch_bounds__(256) void k_lut_build(const uint32_t* __restrict__ 
 		nearest_in(pal + 256, r, g, b, d1, i1);
 		if (!(d0 <= d1)) e = 0x100u | i1;
 	}
-	lut[c] = (uint16_t)e;
+	lut[lut_index(c)] = (uint16_t)e;
 }
 
 // K0b: bit (e2) of row (e1) = palette colours of entries e1 and e2 are within +-2 on R, G and B.
@@ -142,7 +156,7 @@ __global__ __launch_bounds__(256) void k_quantise(const uint32_t* __restrict__ p
 {
 	size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
 	size_t stride = (size_t)gridDim.x * 256;
-	for (; i < n; i += stride) out[i] = lut[pix[i] & 0xFFFFFFu];
+	for (; i < n; i += stride) out[i] = lut[lut_index(pix[i])];
 }
 
 // ----------------------------------------------------------------------------------------------
@@ -183,67 +197,179 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t x)
 // relaxed agent-scope atomics (sc1), so no fence is needed (the data is the flag).
 // Forward progress: tiles are handed out by a ticket counter, so every predecessor of a
 // running tile is itself running or finished.  Spins are bounded; on timeout ctrl[1] is set.
-__device__ __forceinline__ uint32_t lookback(unsigned long long* st, int tile, int lane, uint32_t* ctrl)
+// `pre` is the first window's status word, loaded one frame earlier (latency hidden).
+__device__ __forceinline__ unsigned long long st_load(unsigned long long* st, int idx)
+{
+	return idx >= 0 ? __hip_atomic_load(st + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : ST_PREFIX;
+}
+
+__device__ __forceinline__ uint32_t lookback(unsigned long long* st, int tile, int lane, uint32_t* ctrl,
+                                             unsigned long long pre)
 {
 	uint32_t excl = 0;
 	int j = tile - 1;
+	unsigned long long v = pre;
 	for (;;) {
-		int idx = j - lane;
-		unsigned long long v = ST_PREFIX;          // tiles before the first: prefix 0
+		const int idx = j - lane;
 		unsigned spins = 0;
-		for (;;) {
-			if (idx >= 0) v = __hip_atomic_load(st + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-			if (__all((v >> 32) != 0)) break;
+		while (!__all((v >> 32) != 0)) {
 			__builtin_amdgcn_s_sleep(1);
-			if (++spins > (1u << 24)) {
+			if (++spins > (1u << 22)) {
 				if (lane == 0) atomicExch(ctrl + 1, 1u);
 				return excl;
 			}
+			v = st_load(st, idx);
 		}
-		uint32_t val = (uint32_t)v;
-		unsigned long long pm = __ballot((v >> 32) == 2);
+		const uint32_t val = (uint32_t)v;
+		const unsigned long long pm = __ballot((v >> 32) == 2);
 		if (pm) {
-			int first = __ffsll((long long)pm) - 1;
+			const int first = __ffsll((long long)pm) - 1;
 			excl += wave_sum(lane <= first ? val : 0u);
 			return excl;
 		}
 		excl += wave_sum(val);
 		j -= 64;
+		v = st_load(st, j - lane);
 	}
 }
 
+// cooperative copy of `total` staged bytes to the frame bitstream at byte offset `base`:
+// dword stores on global-aligned dwords (staged byte i lives at stage byte 4+i), bytes at the
+// two ragged ends (which share a dword with the neighbouring tiles).
+__device__ __forceinline__ void copy_out(const uint8_t* stage, uint8_t* gdst, uint32_t total, int tid)
+{
+	const uint32_t s = (uint32_t)((uintptr_t)gdst & 3u);
+	uint8_t* g0 = gdst - s;
+	const uint32_t ndw = (s + total + 3u) >> 2;
+	const uint32_t* s32 = (const uint32_t*)stage;
+	for (uint32_t j = tid; j < ndw; j += ENC_T) {
+		const int lo_i = (int)(4u * j) - (int)s;              // staged index of this dword's byte 0
+		if (lo_i >= 0 && (uint32_t)lo_i + 4u <= total) {
+			const uint32_t lo = s32[j], hi = s32[j + 1];
+			*(uint32_t*)(g0 + 4u * j) = s ? __builtin_amdgcn_alignbyte(hi, lo, 4u - s) : hi;
+		} else {
+#pragma unroll
+			for (int q = 0; q < 4; q++) {
+				const int i = lo_i + q;
+				if (i >= 0 && (uint32_t)i < total) g0[4u * j + q] = stage[4 + i];
+			}
+		}
+	}
+}
+
+constexpr int WBLK = 64;                                       // blocks per wave-tile
+constexpr int WSTAGE = 4 + WBLK * 33 + 12;                     // front pad + worst case + tail pad (2128 B)
+static_assert(WSTAGE % 16 == 0, "stage buffers must stay 16-byte aligned");
+static_assert(WSTAGE >= WBLK * 16 * 2, "the entry transpose buffer aliases a stage buffer");
+
+// wave-wide copy of `total` staged bytes to the frame bitstream (see copy_out above for the scheme)
+__device__ __forceinline__ void wave_copy_out(const uint8_t* stage, uint8_t* gdst, uint32_t total, int lane)
+{
+	const uint32_t s = (uint32_t)((uintptr_t)gdst & 3u);
+	uint8_t* g0 = gdst - s;
+	const uint32_t ndw = (s + total + 3u) >> 2;
+	const uint32_t* s32 = (const uint32_t*)stage;
+	for (uint32_t j = lane; j < ndw; j += 64) {
+		const int lo_i = (int)(4u * j) - (int)s;
+		if (lo_i >= 0 && (uint32_t)lo_i + 4u <= total) {
+			const uint32_t lo = s32[j], hi = s32[j + 1];
+			*(uint32_t*)(g0 + 4u * j) = s ? __builtin_amdgcn_alignbyte(hi, lo, 4u - s) : hi;
+		} else {
+#pragma unroll
+			for (int q = 0; q < 4; q++) {
+				const int i = lo_i + q;
+				if (i >= 0 && (uint32_t)i < total) g0[4u * j + q] = stage[4 + i];
+			}
+		}
+	}
+}
+
+// K1.  One WAVE = one tile of 64 consecutive 4x4 blocks, carried through the <=4 frames of one
+// GOP; the 8 waves of a workgroup only share the LDS bit matrix and run without any workgroup
+// barrier.  Per frame a wave
+//   (Q) quantises with lane = PIXEL: instruction g covers the 16x4-pixel patch of blocks 4g..4g+3,
+//       so the 64 addresses of one LUT gather fall into a handful of 4x4x4 colour cubes (lines);
+//       the entries are transposed to lane = BLOCK through LDS;
+//   (C) classifies its block (FILL / COPY / NORMAL) with one matrix bit per pixel and scans the
+//       block lengths across the wave;
+//   (E) emits the block's bytes into its LDS stage, publishes the tile aggregate, and
+//   (L) one frame later resolves the decoupled look-back of that frame (window prefetched a
+//       frame earlier) and copies the stage to the frame's bitstream.
 template <bool M512>
 __global__ __launch_bounds__(ENC_T, 4) void k_encode(EncArgs A)
 {
 	constexpr int NROWS = M512 ? 512 : 256;
 	extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
 	uint32_t* s_mtx = (uint32_t*)smem;                         // NROWS * MROW dwords
-	uint8_t* s_stage = smem + NROWS * MROW * 4;                // 4 B front pad + ENC_T*33 bytes
-	uint32_t* s_misc = (uint32_t*)(s_stage + 4 + ENC_T * 33 + 12);   // [0..7] wave sums, [8] base, [9] ticket
-	static_assert((4 + ENC_T * 33 + 12) % 16 == 0, "misc must stay aligned");
-
 	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+	uint8_t* s_wave = smem + NROWS * MROW * 4 + wave * (2 * WSTAGE);   // this wave's two stage buffers
 	const uint32_t npx = A.w * A.h;
 
 	for (int i = tid; i < NROWS * MROW; i += ENC_T) s_mtx[i] = A.mtx[i];
+	__syncthreads();                                           // the only workgroup barrier
 
-	for (;;) {
-		__syncthreads();                                       // matrix ready / previous tile fully drained
-		if (tid == 0) s_misc[9] = atomicAdd(A.ctrl, 1u);
-		__syncthreads();
-		const uint32_t t = s_misc[9];
-		if (t >= A.total_tiles) break;
-		const uint32_t group = t / A.tpf, tile = t - group * A.tpf;
-		// batch frames of this GOP: frame_count = first_fc + f, GOP boundary where it is 0 mod 4
+	const uint32_t jb = lane >> 2, prow = lane & 3;            // quantise phase: lane = (block jb of 16, row prow)
+	const __amdgpu_buffer_rsrc_t lut_rs = __builtin_amdgcn_make_buffer_rsrc((void*)A.lut, 0, (int)(LUT_ENTRIES * 2u), 0x00020000);
+
+	// tickets come in chunks of TCHUNK per atomic: one returning atomic word sustains only ~88 dequeues/us
+	// chip-wide (MI355X_MICROARCH "dequeue"), far fewer than the ~260 wave-tiles/us this kernel retires.
+	// Consecutive tickets are the same tile of DIFFERENT GOPs, so the tiles of a chunk never wait on each other.
+	constexpr uint32_t TCHUNK = 8;
+	uint32_t t = 0, t_end;
+	if (lane == 0) t = atomicAdd(A.ctrl, TCHUNK);
+	t = __builtin_amdgcn_readfirstlane(t);
+	t_end = t + TCHUNK;
+	uint32_t t_next = 0;
+	while (t < A.total_tiles) {
+		if (t + 1 == t_end && lane == 0) t_next = atomicAdd(A.ctrl, TCHUNK);   // next chunk: in flight during the last tile
+		// tile-major ticket order: consecutive tickets are the SAME tile of different GOPs, so a
+		// tile's predecessors (same GOP, lower tile) are n_groups tickets older -> mostly finished
+		// and already carrying an inclusive prefix when the look-back reads them.
+		const uint32_t tile = t / A.n_groups, group = t - tile * A.n_groups;
 		const int f_lo = group == 0 ? 0 : (int)(group * 4 - A.phase);
 		int f_hi = (int)(group * 4 - A.phase) + 4;
 		if (f_hi > (int)A.n_frames) f_hi = (int)A.n_frames;
 
-		const uint32_t blk = tile * ENC_T + tid;
+		// lane-as-block geometry (classification, I-frame entry plane)
+		const uint32_t blk = tile * WBLK + lane;
 		const bool valid = blk < A.nblk;
-		const uint32_t b = valid ? blk : A.nblk - 1;
-		const uint32_t by = b / A.bw, bx = b - by * A.bw;
+		const uint32_t bb = valid ? blk : A.nblk - 1;
+		const uint32_t by = bb / A.bw, bx = bb - by * A.bw;
 		const uint32_t poff = by * 4 * A.w + bx * 4;           // top-left pixel of the block
+
+		// quantise geometry, lane = (block, row): load i (0..3) fetches row `prow` (16 bytes) of block
+		// tile*64 + 16i + jb, so one instruction reads four 256-byte row segments of 16 adjacent blocks
+		// (1 KiB, full lines) and each of its four pixel columns is a 64x4-pixel patch for the LUT gather.
+		// Offsets are not kept in registers: a tile inside one block row uses immediate offsets, a tile
+		// crossing one row boundary adds 3*w past it, anything else (frames narrower than 64 blocks, the
+		// ragged last tile) walks the blocks incrementally.
+		const uint32_t B0 = tile * WBLK + jb;
+		const uint32_t Bc0 = B0 < A.nblk ? B0 : A.nblk - 1;
+		const uint32_t qy0 = Bc0 / A.bw, qx0 = Bc0 - qy0 * A.bw;
+		const uint32_t p0b = ((qy0 * 4 + prow) * A.w + qx0 * 4) * 4u, w3b = 12u * A.w;
+		const uint32_t row_first = (tile * WBLK) / A.bw, row_last = (tile * WBLK + WBLK - 1) / A.bw;
+		const uint32_t wrapB = (row_first + 1) * A.bw;          // first block of the next block row
+		const int path = (tile * WBLK + WBLK > A.nblk || row_last > row_first + 1) ? 2 : (row_last != row_first ? 1 : 0);
+		auto load_frame = [&](const uint32_t* fp, uint4 (&dst)[4]) {
+			// uniform 128-bit descriptor per frame + one 32-bit byte offset per lane
+			const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)fp, 0, (int)(npx * 4u), 0x00020000);
+			if (path == 0) {
+#pragma unroll
+				for (int i = 0; i < 4; i++) dst[i] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rs, p0b + 256 * i, 0, 0));
+			} else if (path == 1) {
+#pragma unroll
+				for (int i = 0; i < 4; i++)
+					dst[i] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rs, p0b + 256 * i + (B0 + 16 * i >= wrapB ? w3b : 0u), 0, 0));
+			} else {
+#pragma unroll
+				for (int i = 0; i < 4; i++) {                  // generic: recompute the block position (4 divisions per frame)
+					uint32_t B = B0 + 16 * i;
+					if (B >= A.nblk) B = A.nblk - 1;           // blocks past the frame re-read the last valid one
+					const uint32_t qy = B / A.bw, qx = B - qy * A.bw;
+					dst[i] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rs, ((qy * 4 + prow) * A.w + qx * 4) * 4u, 0, 0));
+				}
+			}
+		};
 
 		uint32_t irow[16];                                     // matrix row (dword index) of the I-frame entries
 		if (((A.first_fc + f_lo) & 3u) != 0) {                 // GOP started in an earlier batch
@@ -259,155 +385,175 @@ __global__ __launch_bounds__(ENC_T, 4) void k_encode(EncArgs A)
 		}
 
 		uint4 px[4];
-		{
-			const uint32_t* fp = A.pix + (size_t)f_lo * npx + poff;
-#pragma unroll
-			for (int r = 0; r < 4; r++) px[r] = *(const uint4*)(fp + r * A.w);
-		}
+		load_frame(A.pix + (size_t)f_lo * npx, px);
 
-		for (int f = f_lo; f < f_hi; f++) {
-			const bool is_i = ((A.first_fc + f) & 3u) == 0;
-			// ---- loop A: colour -> entry through the exact table (16 gathers in flight)
-			uint32_t e[16];
+		uint32_t total_prev = 0;
+		for (int f = f_lo; f <= f_hi; f++) {
+			const bool have_cur = f < f_hi, have_prev = f > f_lo;
+			unsigned long long pre = ST_PREFIX;
+			if (have_prev && tile != 0)                        // prefetch the look-back window of frame f-1
+				pre = st_load(A.status + (size_t)(f - 1) * A.tpf, (int)tile - 1 - lane);
+
+			uint32_t total = 0;
+			if (have_cur) {
+				const bool is_i = ((A.first_fc + f) & 3u) == 0;
+				uint8_t* stage = s_wave + (f & 1) * WSTAGE;
+				// ---- (Q) colour -> entry through the exact table, lane = (block, row)
+				uint32_t eq[16];
 #pragma unroll
-			for (int r = 0; r < 4; r++) {
-				e[r * 4 + 0] = A.lut[px[r].x & 0xFFFFFFu]; e[r * 4 + 1] = A.lut[px[r].y & 0xFFFFFFu];
-				e[r * 4 + 2] = A.lut[px[r].z & 0xFFFFFFu]; e[r * 4 + 3] = A.lut[px[r].w & 0xFFFFFFu];
-			}
-			if (f + 1 < f_hi) {                                // prefetch the next frame of the GOP
-				const uint32_t* fp = A.pix + (size_t)(f + 1) * npx + poff;
+				for (int i = 0; i < 4; i++) {
+#ifdef ABL_NOGATHER
+					eq[i * 4 + 0] = px[i].x & 0x1FFu; eq[i * 4 + 1] = px[i].y & 0x1FFu;
+					eq[i * 4 + 2] = px[i].z & 0x1FFu; eq[i * 4 + 3] = px[i].w & 0x1FFu;
+#else
+					eq[i * 4 + 0] = (uint16_t)__builtin_amdgcn_raw_buffer_load_b16(lut_rs, lut_index(px[i].x) * 2u, 0, 0);
+					eq[i * 4 + 1] = (uint16_t)__builtin_amdgcn_raw_buffer_load_b16(lut_rs, lut_index(px[i].y) * 2u, 0, 0);
+					eq[i * 4 + 2] = (uint16_t)__builtin_amdgcn_raw_buffer_load_b16(lut_rs, lut_index(px[i].z) * 2u, 0, 0);
+					eq[i * 4 + 3] = (uint16_t)__builtin_amdgcn_raw_buffer_load_b16(lut_rs, lut_index(px[i].w) * 2u, 0, 0);
+#endif
+				}
+				if (f + 1 < f_hi) load_frame(A.pix + (size_t)(f + 1) * npx, px);   // prefetch the next frame of the GOP
+				// [block][pixel] u16 table, aliases the stage (dead until E); lane writes its row: 8 bytes at lane*8 + i*512
 #pragma unroll
-				for (int r = 0; r < 4; r++) px[r] = *(const uint4*)(fp + r * A.w);
-			}
-			// ---- loop B: block tests. count1 = CompareIFrameBlock vs the top-left entry colour
-			// (src/agmv_encode.c:302-352), count2 = ComparePFrameBlock vs the I-frame entries
-			// (src/agmv_encode.c:240-300); one matrix bit per pixel.
-			const uint32_t row0 = e[0] * MROW;
-			uint32_t acc1 = 0, acc2 = 0, nesc = 0;
-#pragma unroll
-			for (int k = 0; k < 16; k++) {
-				uint32_t w1 = s_mtx[row0 + (e[k] >> 5)];
-				acc1 = __builtin_amdgcn_alignbit(w1 >> (e[k] & 31u), acc1, 1);
-				if (M512) nesc += ((e[k] & 0xffu) >= 127u) ? 1u : 0u;
-			}
-			if (!is_i) {
+				for (int i = 0; i < 4; i++) {
+					uint2 q;
+					q.x = eq[i * 4 + 0] | (eq[i * 4 + 1] << 16);
+					q.y = eq[i * 4 + 2] | (eq[i * 4 + 3] << 16);
+					*(uint2*)(stage + i * 512 + lane * 8) = q;
+				}
+				__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+				__builtin_amdgcn_wave_barrier();
+				// ---- transpose: lane = block reads its 16 entries (32 contiguous bytes)
+				uint32_t e[16];
+				{
+					const uint4 lo = *(const uint4*)(stage + lane * 32), hi = *(const uint4*)(stage + lane * 32 + 16);
+					e[0] = lo.x & 0xffffu; e[1] = lo.x >> 16; e[2] = lo.y & 0xffffu; e[3] = lo.y >> 16;
+					e[4] = lo.z & 0xffffu; e[5] = lo.z >> 16; e[6] = lo.w & 0xffffu; e[7] = lo.w >> 16;
+					e[8] = hi.x & 0xffffu; e[9] = hi.x >> 16; e[10] = hi.y & 0xffffu; e[11] = hi.y >> 16;
+					e[12] = hi.z & 0xffffu; e[13] = hi.z >> 16; e[14] = hi.w & 0xffffu; e[15] = hi.w >> 16;
+				}
+				__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+				__builtin_amdgcn_wave_barrier();
+				// ---- (C) block tests. count1 = CompareIFrameBlock vs the top-left entry colour
+				// (src/agmv_encode.c:302-352), count2 = ComparePFrameBlock vs the I-frame entries
+				// (src/agmv_encode.c:240-300); one matrix bit per pixel.
+				const uint32_t row0 = e[0] * MROW;
+				uint32_t acc1 = 0, acc2 = 0, nesc = 0;
 #pragma unroll
 				for (int k = 0; k < 16; k++) {
-					uint32_t w2 = s_mtx[irow[k] + (e[k] >> 5)];
-					acc2 = __builtin_amdgcn_alignbit(w2 >> (e[k] & 31u), acc2, 1);
+#ifdef ABL_NOCMP
+					uint32_t w1 = e[k] * 0x9E3779B1u;
+#else
+					uint32_t w1 = s_mtx[row0 + (e[k] >> 5)];
+#endif
+					acc1 = __builtin_amdgcn_alignbit(w1 >> (e[k] & 31u), acc1, 1);
+					if (M512) nesc += ((e[k] & 0xffu) >= 127u) ? 1u : 0u;
 				}
-			}
-			const uint32_t count1 = __popc(acc1), count2 = __popc(acc2);
-			const bool copy = !is_i && count2 >= COPY_COUNT;       // COPY has priority, :465
-			const bool fill = !copy && count1 >= FILL_COUNT;
-			uint32_t len;
-			if (copy) len = 1;
-			else if (fill) len = M512 ? (2u + ((e[0] & 0xffu) >= 127u ? 1u : 0u)) : 2u;
-			else len = 17u + nesc;
-			if (!valid) len = 0;
-
-			if (is_i) {                                            // iframe_entries = img_entry, :626-630
-#pragma unroll
-				for (int k = 0; k < 16; k++) irow[k] = e[k] * MROW;
-				if (A.ientries && (uint32_t)f == A.last_iframe && valid) {
-#pragma unroll
-					for (int r = 0; r < 4; r++) {
-						uint2 q;
-						q.x = e[r * 4 + 0] | (e[r * 4 + 1] << 16);
-						q.y = e[r * 4 + 2] | (e[r * 4 + 3] << 16);
-						*(uint2*)(A.ientries + poff + r * A.w) = q;
-					}
-				}
-			}
-
-			// ---- byte offsets: wave scan -> workgroup scan -> look-back across tiles
-			const uint32_t incl = wave_incl_scan(len, lane);
-			if (lane == 63) s_misc[wave] = incl;
-			__syncthreads();                                       // (A)
-			uint32_t woff = 0, total = 0;
-#pragma unroll
-			for (int i = 0; i < ENC_WAVES; i++) {
-				uint32_t s = s_misc[i];
-				if (i < wave) woff += s;
-				total += s;
-			}
-			unsigned long long* st = A.status + (size_t)f * A.tpf;
-			if (wave == 0 && lane == 0) {
-				unsigned long long v = (tile == 0 ? ST_PREFIX : ST_AGG) | total;
-				__hip_atomic_store(st + tile, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-			}
-
-			// ---- emit this block's bytes into the LDS stage (independent of the global base)
-			if (valid) {
-				uint8_t* sp = s_stage + 4 + woff + incl - len;
-				if (copy) {
-					sp[0] = COPY_FLAG;
-				} else if (fill) {
-					sp[0] = FILL_FLAG;
-					if (M512) {
-						uint32_t idx = e[0] & 0xffu, p7 = (e[0] >> 1) & 0x80u;
-						sp[1] = (uint8_t)(p7 | (idx < 127u ? idx : 127u));        // :382-388
-						if (idx >= 127u) sp[2] = (uint8_t)idx;
-					} else {
-						sp[1] = (uint8_t)e[0];                                     // :421
-					}
-				} else {
-					sp[0] = NORMAL_FLAG;
-					uint32_t pos = 1;
+				if (!is_i) {
 #pragma unroll
 					for (int k = 0; k < 16; k++) {
-						if (M512) {
-							uint32_t idx = e[k] & 0xffu, p7 = (e[k] >> 1) & 0x80u;
-							sp[pos] = (uint8_t)(p7 | (idx < 127u ? idx : 127u));    // :395-401
-							if (idx >= 127u) sp[pos + 1] = (uint8_t)idx;
-							pos += 1u + (idx >= 127u ? 1u : 0u);
-						} else {
-							sp[pos++] = (uint8_t)e[k];                             // :428-429
+#ifdef ABL_NOCMP
+						uint32_t w2 = (e[k] ^ irow[k]) * 0x9E3779B1u;
+#else
+						uint32_t w2 = s_mtx[irow[k] + (e[k] >> 5)];
+#endif
+						acc2 = __builtin_amdgcn_alignbit(w2 >> (e[k] & 31u), acc2, 1);
+					}
+				}
+				const uint32_t count1 = __popc(acc1), count2 = __popc(acc2);
+				const bool copy = !is_i && count2 >= COPY_COUNT;   // COPY has priority, :465
+				const bool fill = !copy && count1 >= FILL_COUNT;
+				uint32_t len;
+				if (copy) len = 1;
+				else if (fill) len = M512 ? (2u + ((e[0] & 0xffu) >= 127u ? 1u : 0u)) : 2u;
+				else len = 17u + nesc;
+				if (!valid) len = 0;
+
+				if (is_i) {                                        // iframe_entries = img_entry, :626-630
+#pragma unroll
+					for (int k = 0; k < 16; k++) irow[k] = e[k] * MROW;
+					if (A.ientries && (uint32_t)f == A.last_iframe && valid) {
+#pragma unroll
+						for (int r = 0; r < 4; r++) {
+							uint2 q;
+							q.x = e[r * 4 + 0] | (e[r * 4 + 1] << 16);
+							q.y = e[r * 4 + 2] | (e[r * 4 + 3] << 16);
+							*(uint2*)(A.ientries + poff + r * A.w) = q;
 						}
 					}
 				}
+
+				// ---- byte offsets inside the tile: wave scan; publish the tile aggregate
+				const uint32_t incl = wave_incl_scan(len, lane);
+				total = __shfl(incl, 63, 64);
+				if (lane == 0) {
+					unsigned long long v = (tile == 0 ? ST_PREFIX : ST_AGG) | total;
+					__hip_atomic_store(A.status + (size_t)f * A.tpf + tile, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				}
+
+				// ---- (E) emit this block's bytes into the LDS stage (independent of the global base)
+#ifdef ABL_NOEMIT
+				if (valid && len == 0xFFFFu) {
+#else
+				if (valid) {
+#endif
+					uint8_t* sp = stage + 4 + incl - len;
+					if (copy) {
+						sp[0] = COPY_FLAG;
+					} else if (fill) {
+						sp[0] = FILL_FLAG;
+						if (M512) {
+							uint32_t idx = e[0] & 0xffu, p7 = (e[0] >> 1) & 0x80u;
+							sp[1] = (uint8_t)(p7 | (idx < 127u ? idx : 127u));        // :382-388
+							if (idx >= 127u) sp[2] = (uint8_t)idx;
+						} else {
+							sp[1] = (uint8_t)e[0];                                     // :421
+						}
+					} else {
+						sp[0] = NORMAL_FLAG;
+						uint32_t pos = 1;
+#pragma unroll
+						for (int k = 0; k < 16; k++) {
+							if (M512) {
+								uint32_t idx = e[k] & 0xffu, p7 = (e[k] >> 1) & 0x80u;
+								sp[pos] = (uint8_t)(p7 | (idx < 127u ? idx : 127u));    // :395-401
+								if (idx >= 127u) sp[pos + 1] = (uint8_t)idx;
+								pos += 1u + (idx >= 127u ? 1u : 0u);
+							} else {
+								sp[pos++] = (uint8_t)e[k];                             // :428-429
+							}
+						}
+					}
+				}
+				__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+				__builtin_amdgcn_wave_barrier();
 			}
 
-			if (wave == 0) {
+			// ---- (L) resolve frame f-1: look-back, then copy its stage out
+			if (have_prev) {
+				unsigned long long* st = A.status + (size_t)(f - 1) * A.tpf;
 				uint32_t excl = 0;
+#ifdef ABL_NOLOOKBACK
+				if (false) {
+#else
 				if (tile != 0) {
-					excl = lookback(st, (int)tile, lane, A.ctrl);
+#endif
+					excl = lookback(st, (int)tile, lane, A.ctrl, pre);
 					if (lane == 0)
-						__hip_atomic_store(st + tile, ST_PREFIX | (unsigned long long)(excl + total),
+						__hip_atomic_store(st + tile, ST_PREFIX | (unsigned long long)(excl + total_prev),
 						                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 				}
-				if (lane == 0) {
-					s_misc[8] = excl;
-					if (tile == A.tpf - 1) A.sizes[f] = excl + total;   // usize of the frame
-				}
+				if (lane == 0 && tile == A.tpf - 1) A.sizes[f - 1] = excl + total_prev;   // usize of the frame
+#ifdef ABL_NOEMIT
+				if (total_prev == 0xFFFFFFFFu)
+#endif
+				wave_copy_out(s_wave + ((f - 1) & 1) * WSTAGE, A.out + (size_t)(f - 1) * A.out_stride + excl, total_prev, lane);
+				__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+				__builtin_amdgcn_wave_barrier();
 			}
-			__syncthreads();                                       // (B) stage + base ready
-
-			// ---- cooperative copy stage -> frame bitstream, dword-wide on global-aligned dwords
-			{
-				const uint32_t base = s_misc[8];
-				uint8_t* gdst = A.out + (size_t)f * A.out_stride + base;
-				const uint32_t s = (uint32_t)((uintptr_t)gdst & 3u);
-				uint8_t* g0 = gdst - s;
-				const uint32_t ndw = (s + total + 3u) >> 2;
-				const uint32_t* s32 = (const uint32_t*)s_stage;   // staged byte i lives at byte 4+i
-				for (uint32_t j = tid; j < ndw; j += ENC_T) {
-					const int lo_i = (int)(4u * j) - (int)s;          // staged index of this dword's byte 0
-					if (lo_i >= 0 && (uint32_t)lo_i + 4u <= total) {
-						uint32_t lo = s32[j], hi = s32[j + 1];
-						uint32_t v = s ? __builtin_amdgcn_alignbyte(hi, lo, 4u - s) : hi;
-						*(uint32_t*)(g0 + 4u * j) = v;
-					} else {
-#pragma unroll
-						for (int q = 0; q < 4; q++) {
-							int i = lo_i + q;
-							if (i >= 0 && (uint32_t)i < total) g0[4u * j + q] = s_stage[4 + i];
-						}
-					}
-				}
-			}
-			__syncthreads();                                       // (C) stage may be overwritten
+			total_prev = total;
 		}
+		if (++t == t_end) { t = __builtin_amdgcn_readfirstlane(t_next); t_end = t + TCHUNK; }
 	}
 }
 
@@ -461,6 +607,231 @@ __global__ __launch_bounds__(64) void k_parse_serial(const uint8_t* __restrict__
 		}
 	}
 	nentered[f] = k;
+}
+
+// ----------------------------------------------------------------------------------------------
+// K2 (parallel form).  The block loop of the reference (src/agmv_decode.c:226-320) is a chain:
+// block k+1 is entered where block k ended.  Every byte position p <= bpos is a chain node:
+//   not a flag  -> next = p+1, counts 0 blocks                      (the resync of :236-243)
+//   COPY        -> next = p+1
+//   FILL        -> next = p+1+c(p+1)        c(q) = 1, or 2 if (byte[q]&0x7f)==127 (512 colours)
+//   NORMAL      -> next = 16 codes after p+1 (found by 4 rounds of pointer doubling over c)
+// and block k+1's entry offset is next(flag node of block k).  next(p)-p <= 33, so a chunk of
+// 1024 positions is summarised by a map {entry offset 0..32} -> (exit offset, blocks counted),
+// built with 10 rounds of pointer doubling in LDS (k_parse_chunks).  One wave per frame then
+// threads the chunks together with shuffles (k_parse_stitch), and k_parse_emit marks the true
+// chain top-down through the stored doubling levels and writes the entry offsets.
+// ----------------------------------------------------------------------------------------------
+constexpr int PC = 1024;        // positions per chunk
+constexpr int PT = 256;         // threads per chunk workgroup
+constexpr int PPT = PC / PT;    // positions per thread
+constexpr int PLV = 10;         // doubling levels: 2^10 nodes >= nodes in a chunk
+constexpr int PHALO = 64;       // bytes staged beyond the chunk (a block spans <= 33)
+constexpr uint32_t P_END = 0xFFFFu;   // chain left the readable stream (position > bpos)
+
+struct ParseArgs {
+	const uint8_t* bits;
+	unsigned long long stride;
+	const uint32_t* bpos;
+	uint32_t* cum;          // [n_frames+1] exclusive prefix of chunks per frame
+	uint32_t* summ;         // [chunk][33] exit<<16 | count   (exit 0xff: chain ended in the chunk)
+	uint32_t* centry;       // [chunk] kbase<<8 | entry offset (0xff: chain never reaches the chunk)
+	uint32_t* offsets;
+	uint32_t* nentered;
+	uint32_t n_frames, nblk;
+};
+
+__global__ __launch_bounds__(64) void k_parse_prefix(ParseArgs A)
+{
+	const int lane = threadIdx.x;
+	uint32_t run = 0;
+	for (uint32_t f0 = 0; f0 < A.n_frames; f0 += 64) {
+		const uint32_t f = f0 + lane;
+		const uint32_t x = f < A.n_frames ? (A.bpos[f] + PC) / PC : 0u;     // ceil((bpos+1)/PC)
+		const uint32_t incl = wave_incl_scan(x, lane);
+		if (f < A.n_frames) A.cum[f] = run + incl - x;
+		run += __shfl(incl, 63, 64);
+	}
+	if (lane == 0) A.cum[A.n_frames] = run;
+}
+
+__device__ __forceinline__ uint32_t find_frame(const uint32_t* cum, uint32_t n, uint32_t g)
+{
+	uint32_t lo = 0, hi = n;                                   // largest f with cum[f] <= g
+	while (hi - lo > 1) {
+		const uint32_t mid = (lo + hi) >> 1;
+		if (cum[mid] <= g) lo = mid; else hi = mid;
+	}
+	return lo;
+}
+
+// LDS layout shared by k_parse_chunks / k_parse_emit
+struct ParseLds {
+	uint8_t b[PC + PHALO];          // staged bytes
+	uint8_t ca[PC + PHALO];         // code-run lengths, ping
+	uint8_t cb[PC + PHALO];         // code-run lengths, pong
+	uint8_t d[PC];                  // bits 0..5 next(p)-p, bit 7 = node counts one block
+	uint16_t N[2][PC];              // blocks counted along the chain, ping-pong
+};
+
+// builds d[] and the doubling levels J[0..PLV] (level i = position after 2^i nodes, >= PC once the
+// chain left the chunk, P_END once it left the stream).  With KEEP every level has its own table,
+// otherwise two tables ping-pong.  Returns the index (0/1) of the final N table.
+template <bool M512, bool KEEP>
+__device__ __forceinline__ int parse_chunk_tables(ParseLds& S, uint16_t (*J)[PC], const uint8_t* fbits, uint32_t cap,
+                                                  uint32_t bpos, uint32_t cs, int tid)
+{
+	// ---- stage the chunk (+halo), dword-wide (cs is a multiple of 1024, the slab 4-byte aligned)
+	for (int i = tid; i < (PC + PHALO) / 4; i += PT) {
+		const uint32_t pos = cs + 4u * i;
+		uint32_t v = 0;
+		if (pos + 4u <= cap) v = *(const uint32_t*)(fbits + pos);
+		else
+			for (uint32_t q = 0; q < 4; q++)
+				if (pos + q < cap) v |= (uint32_t)fbits[pos + q] << (8 * q);
+		((uint32_t*)S.b)[i] = v;
+	}
+	__syncthreads();
+	if (M512) {
+		// c1 -> c2 -> c4 -> c8 -> c16 : bytes taken by 1,2,4,8,16 consecutive entry codes
+		for (int i = tid; i < PC + PHALO; i += PT) S.ca[i] = (uint8_t)(1u + ((S.b[i] & 0x7fu) == 127u ? 1u : 0u));
+		__syncthreads();
+		uint8_t* src = S.ca;
+		uint8_t* dst = S.cb;
+		int lim = PC + PHALO;
+#pragma unroll
+		for (int r = 0; r < 4; r++) {
+			lim -= 2 << r;                                     // indices whose partner is still inside the staged range
+			for (int i = tid; i < lim; i += PT) { const uint32_t a = src[i]; dst[i] = (uint8_t)(a + src[i + a]); }
+			__syncthreads();
+			uint8_t* t = src; src = dst; dst = t;
+		}
+		// after 4 swaps src == S.ca holds c16; c1 must be recomputed from b where needed
+	}
+	// ---- node table
+	for (int q = 0; q < PPT; q++) {
+		const int p = tid + q * PT;
+		const uint32_t byte = S.b[p];
+		uint32_t delta = 1, counts = 0;
+		if (byte == COPY_FLAG) { counts = 1; }
+		else if (byte == FILL_FLAG) { counts = 1; delta = M512 ? 2u + ((S.b[p + 1] & 0x7fu) == 127u ? 1u : 0u) : 2u; }
+		else if (byte == NORMAL_FLAG) { counts = 1; delta = M512 ? 1u + S.ca[p + 1] : 17u; }
+		const uint32_t ap = cs + p;                            // absolute position
+		uint32_t j;
+		if (ap > bpos) { j = P_END; counts = 0; }              // not a node
+		else if (ap + delta > bpos) { j = P_END; counts = 0; } // block k+1 would be entered beyond bpos: not entered
+		else j = p + delta;                                    // < PC: inside, else exit offset + PC
+		S.d[p] = (uint8_t)(delta | (counts << 7));
+		J[0][p] = (uint16_t)j;
+		S.N[0][p] = (uint16_t)counts;
+	}
+	__syncthreads();
+	int cur = 0;
+#pragma unroll 1
+	for (int lv = 0; lv < PLV; lv++) {
+		uint16_t* Js = KEEP ? J[lv] : J[lv & 1];
+		uint16_t* Jd = KEEP ? J[lv + 1] : J[(lv + 1) & 1];
+		for (int q = 0; q < PPT; q++) {
+			const int p = tid + q * PT;
+			const uint32_t j = Js[p];
+			uint32_t n = S.N[cur][p], jj = j;
+			if (j < (uint32_t)PC) { jj = Js[j]; n += S.N[cur][j]; }
+			Jd[p] = (uint16_t)jj;
+			S.N[cur ^ 1][p] = (uint16_t)n;
+		}
+		__syncthreads();
+		cur ^= 1;
+	}
+	return cur;
+}
+
+template <bool M512>
+__global__ __launch_bounds__(PT) void k_parse_chunks(ParseArgs A)
+{
+	__shared__ ParseLds S;
+	__shared__ uint16_t J[2][PC];
+	const int tid = threadIdx.x;
+	const uint32_t total = A.cum[A.n_frames];
+	for (uint32_t g = blockIdx.x; g < total; g += gridDim.x) {
+		const uint32_t f = find_frame(A.cum, A.n_frames, g);
+		const uint32_t cs = (g - A.cum[f]) * PC, bpos = A.bpos[f];
+		const int cur = parse_chunk_tables<M512, false>(S, J, A.bits + (size_t)f * A.stride, (uint32_t)A.stride, bpos, cs, tid);
+		if (tid < 33) {
+			const uint32_t j = J[PLV & 1][tid];
+			const uint32_t ex = (j == P_END || cs + tid > bpos) ? 0xFFu : j - PC;
+			A.summ[(size_t)g * 33 + tid] = ex << 16 | S.N[cur][tid];
+		}
+		__syncthreads();
+	}
+}
+
+// one wave per frame: thread the chunk maps together.  Rows are fetched 8 chunks ahead (lane j holds
+// map[j]); the dependent step is a shuffle, not a memory access.
+__global__ __launch_bounds__(64) void k_parse_stitch(ParseArgs A)
+{
+	const uint32_t f = blockIdx.x;
+	const int lane = threadIdx.x;
+	const uint32_t c0 = A.cum[f], nch = A.cum[f + 1] - c0;
+	uint32_t o = 0, kb = 0;
+	for (uint32_t c = 0; c < nch; c += 8) {
+		uint32_t row[8];
+#pragma unroll
+		for (int u = 0; u < 8; u++)
+			row[u] = (c + u < nch && lane < 33) ? A.summ[(size_t)(c0 + c + u) * 33 + lane] : 0u;
+#pragma unroll
+		for (int u = 0; u < 8; u++) {
+			if (c + u < nch) {
+				if (lane == 0) A.centry[c0 + c + u] = kb << 8 | o;
+				if (o != 0xFFu) {
+					const uint32_t v = __shfl(row[u], (int)o, 64);
+					kb += v & 0xFFFFu;
+					o = v >> 16;
+				}
+			}
+		}
+	}
+	if (lane == 0) A.nentered[f] = min(A.nblk, kb + 1u);
+}
+
+template <bool M512>
+__global__ __launch_bounds__(PT) void k_parse_emit(ParseArgs A)
+{
+	__shared__ ParseLds S;
+	__shared__ uint16_t J[PLV + 1][PC];
+	__shared__ uint8_t mark[PC];
+	const int tid = threadIdx.x;
+	const uint32_t total = A.cum[A.n_frames];
+	for (uint32_t g = blockIdx.x; g < total; g += gridDim.x) {
+		const uint32_t ce = A.centry[g], o = ce & 0xFFu, kb = ce >> 8;
+		const uint32_t f = find_frame(A.cum, A.n_frames, g);
+		uint32_t* off = A.offsets + (size_t)f * A.nblk;
+		if (g == A.cum[f] && tid == 0) off[0] = 0;             // block 0 is entered at byte 0
+		if (o == 0xFFu) continue;                              // the chain ended before this chunk (uniform)
+		const uint32_t cs = (g - A.cum[f]) * PC, bpos = A.bpos[f];
+		const int cur = parse_chunk_tables<M512, true>(S, J, A.bits + (size_t)f * A.stride, (uint32_t)A.stride, bpos, cs, tid);
+		for (int q = 0; q < PPT; q++) mark[tid + q * PT] = 0;
+		__syncthreads();
+		if (tid == 0) mark[o] = 1;
+		__syncthreads();
+#pragma unroll 1
+		for (int lv = PLV - 1; lv >= 0; lv--) {                // every node 2^lv steps behind a marked one
+			for (int q = 0; q < PPT; q++) {
+				const int p = tid + q * PT;
+				if (mark[p]) { const uint32_t j = J[lv][p]; if (j < (uint32_t)PC) mark[j] = 1; }
+			}
+			__syncthreads();
+		}
+		const uint32_t ntot = S.N[cur][o];
+		for (int q = 0; q < PPT; q++) {
+			const int p = tid + q * PT;
+			const uint32_t d = S.d[p];
+			if (mark[p] && (d & 0x80u)) {
+				const uint32_t k = kb + (ntot - S.N[cur][p]) + 1u;       // this node is block k-1; it ends where block k starts
+				if (k < A.nblk) off[k] = cs + p + (d & 0x3Fu);
+			}
+		}
+		__syncthreads();
+	}
 }
 
 struct DecArgs {
@@ -637,7 +1008,10 @@ __global__ __launch_bounds__(DEC_T) void k_decode(DecArgs A)
 		}
 		if (valid) {
 			store_block(A.out + (size_t)f * npx, poff, A.w, cur);
-			if (stale) atomicOr(A.dirty + (blk >> 5), 1u << (blk & 31u));
+			if (stale) {
+				atomicOr(A.dirty + (blk >> 5), 1u << (blk & 31u));
+				A.dirty[(A.nblk + 31) >> 5] = 1u;                   // "anything to repair" word behind the bitmap
+			}
 		}
 	}
 }
@@ -650,34 +1024,46 @@ __global__ __launch_bounds__(64) void k_fixup(DecArgs A)
 {
 	__shared__ uint32_t s_pal[512];
 	__shared__ uint32_t s_list[64];
-	__shared__ uint32_t s_cnt, s_next;
+	__shared__ uint32_t s_w[64];
+	__shared__ uint32_t s_cnt, s_next, s_more;
 	const int lane = threadIdx.x;
 	const uint32_t npx = A.w * A.h;
+	const uint32_t nwords = (A.nblk + 31) >> 5;
+	if (A.dirty[nwords] == 0) return;                          // nothing depends on an earlier GOP: done
 	for (int i = lane; i < 512; i += 64) s_pal[i] = A.pal[i];
 	if (lane == 0) s_next = 0;
 	__syncthreads();
-	const uint32_t nwords = (A.nblk + 31) >> 5;
 	for (;;) {
-		// ---- collect the next (up to 64) dirty positions, in increasing order (lane 0 does it)
-		if (lane == 0) {
-			uint32_t cnt = 0, pos = s_next;
-			while (pos < A.nblk && cnt < 64) {
-				uint32_t wd = A.dirty[pos >> 5] >> (pos & 31u);
-				if (wd == 0) { pos = (pos | 31u) + 1; continue; }
-				pos += (uint32_t)__ffs((int)wd) - 1;
-				if (pos >= A.nblk) break;
-				if (pos == A.nblk - 1 && A.nblk >= 2 && (cnt == 0 || s_list[cnt - 1] != A.nblk - 2)) {
-					if (cnt >= 63) break;                          // keep the pair in one pass
-					s_list[cnt++] = A.nblk - 2;
-				}
-				s_list[cnt++] = pos;
-				pos++;
-			}
-			s_cnt = cnt;
-			s_next = pos;
-			(void)nwords;
-		}
+		// ---- collect the next (up to 64) dirty positions in increasing order: 64 bitmap words per
+		// step are fetched by the whole wave, lane 0 walks their bits out of LDS
+		if (lane == 0) { s_cnt = 0; s_more = 1; }
 		__syncthreads();
+		while (s_more) {
+			const uint32_t pos0 = s_next, wbase = pos0 >> 5;
+			s_w[lane] = (wbase + lane < nwords) ? A.dirty[wbase + lane] : 0u;
+			__syncthreads();
+			if (lane == 0) {
+				uint32_t cnt = s_cnt, pos = pos0;
+				const uint32_t lim = min(A.nblk, (wbase + 64u) << 5);
+				bool full = false;
+				while (pos < lim) {
+					uint32_t wd = s_w[(pos >> 5) - wbase] >> (pos & 31u);
+					if (wd == 0) { pos = (pos | 31u) + 1; continue; }
+					pos += (uint32_t)__ffs((int)wd) - 1;
+					if (pos >= lim) break;
+					const bool pair = pos == A.nblk - 1 && A.nblk >= 2 && (cnt == 0 || s_list[cnt - 1] != A.nblk - 2);
+					if (cnt + (pair ? 2u : 1u) > 64u) { full = true; break; }   // keep the pair in one pass
+					if (pair) s_list[cnt++] = A.nblk - 2;
+					s_list[cnt++] = pos;
+					pos++;
+				}
+				if (pos > A.nblk) pos = A.nblk;
+				s_cnt = cnt;
+				s_next = pos;
+				s_more = (!full && cnt < 64 && pos < A.nblk) ? 1u : 0u;
+			}
+			__syncthreads();
+		}
 		const uint32_t cnt = s_cnt;
 		if (cnt == 0) break;
 		const bool active = (uint32_t)lane < cnt;
@@ -822,6 +1208,7 @@ extern "C" agmv_hip_ctx* agmv_hip_create(int device)
 	CKP(hipMalloc(&c->d_ctrl, 16));
 	hipDeviceProp_t prop;
 	CKP(hipGetDeviceProperties(&prop, device));
+	c->n_cu = prop.multiProcessorCount;
 	c->enc_grid = prop.multiProcessorCount * 2;               // 2 workgroups of 512 per CU (LDS/VGPR bound)
 	return c;
 }
@@ -831,7 +1218,7 @@ extern "C" void agmv_hip_destroy(agmv_hip_ctx* c)
 	if (!c) return;
 	(void)hipSetDevice(c->device);
 	(void)hipFree(c->d_lut); (void)hipFree(c->d_mtx); (void)hipFree(c->d_pal); (void)hipFree(c->d_ctrl);
-	(void)hipFree(c->d_status); (void)hipFree(c->d_dirty);
+	(void)hipFree(c->d_status); (void)hipFree(c->d_dirty); (void)hipFree(c->d_parse_ws);
 	free(c);
 }
 
@@ -901,7 +1288,7 @@ extern "C" int agmv_hip_encode_frames_dev(agmv_hip_ctx* c, const uint32_t* d_pix
 	A.pix = d_pix; A.out = d_out; A.sizes = d_sizes; A.lut = c->d_lut; A.mtx = c->d_mtx; A.ientries = d_ientries;
 	A.out_stride = out_stride;
 	A.n_frames = n_frames; A.w = w; A.h = h; A.bw = w / 4; A.nblk = (w / 4) * (h / 4);
-	A.tpf = (A.nblk + ENC_T - 1) / ENC_T;
+	A.tpf = (A.nblk + WBLK - 1) / WBLK;
 	A.first_fc = first_fc; A.phase = first_fc & 3u;
 	A.n_groups = (n_frames + A.phase + 3) / 4;
 	A.total_tiles = A.n_groups * A.tpf;
@@ -923,12 +1310,13 @@ extern "C" int agmv_hip_encode_frames_dev(agmv_hip_ctx* c, const uint32_t* d_pix
 	CK(hipMemsetAsync(c->d_status, 0, need * sizeof(unsigned long long), s));
 	CK(hipMemsetAsync(c->d_ctrl, 0, 16, s));
 	uint32_t grid = (uint32_t)c->enc_grid;
-	if (grid > A.total_tiles) grid = A.total_tiles;
+	if (grid > (A.total_tiles + ENC_WAVES - 1) / ENC_WAVES) grid = (A.total_tiles + ENC_WAVES - 1) / ENC_WAVES;
+	const size_t lds = (size_t)(c->mode512 ? 512 : 256) * MROW * 4 + (size_t)ENC_WAVES * 2 * WSTAGE;
 	if (c->mode512) {
-		size_t lds = 512 * MROW * 4 + 4 + ENC_T * 33 + 12 + 64;
+		CK(hipFuncSetAttribute((const void*)k_encode<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
 		hipLaunchKernelGGL(k_encode<true>, dim3(grid), dim3(ENC_T), lds, s, A);
 	} else {
-		size_t lds = 256 * MROW * 4 + 4 + ENC_T * 33 + 12 + 64;
+		CK(hipFuncSetAttribute((const void*)k_encode<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
 		hipLaunchKernelGGL(k_encode<false>, dim3(grid), dim3(ENC_T), lds, s, A);
 	}
 	CK(hipGetLastError());
@@ -985,8 +1373,38 @@ extern "C" int agmv_hip_parse_frames_dev(agmv_hip_ctx* c, const uint8_t* d_bits,
 	if (check_geometry(w, h)) return -1;
 	if (n_frames == 0) return 0;
 	uint32_t nblk = (w / 4) * (h / 4);
-	hipLaunchKernelGGL(k_parse_serial, dim3((n_frames + 63) / 64), dim3(64), 0, (hipStream_t)stream, d_bits,
-	                   (unsigned long long)stride, d_bpos, n_frames, nblk, c->mode512, d_offsets, d_nentered);
+	hipStream_t s = (hipStream_t)stream;
+	const char* mode = getenv("AGMV_HIP_PARSE");
+	if (mode && strcmp(mode, "serial") == 0) {                 // debugging aid: one lane per frame
+		hipLaunchKernelGGL(k_parse_serial, dim3((n_frames + 63) / 64), dim3(64), 0, s, d_bits,
+		                   (unsigned long long)stride, d_bpos, n_frames, nblk, c->mode512, d_offsets, d_nentered);
+		CK(hipGetLastError());
+		return 0;
+	}
+	if ((stride & 3u) || ((uintptr_t)d_bits & 3u)) { snprintf(g_err, sizeof(g_err), "agmv_hip: bitstream slab and stride must be 4-byte aligned"); return -1; }
+	const size_t cpf = (stride + PC) / PC, maxchunks = cpf * n_frames;
+	const size_t need = (size_t)n_frames + 1 + maxchunks + maxchunks * 33 + 16;
+	if (need > c->parse_ws_cap) {
+		if (c->d_parse_ws) CK(hipFree(c->d_parse_ws));
+		c->d_parse_ws = nullptr; c->parse_ws_cap = 0;
+		CK(hipMalloc(&c->d_parse_ws, need * 4));
+		c->parse_ws_cap = need;
+	}
+	ParseArgs A;
+	memset(&A, 0, sizeof(A));
+	A.bits = d_bits; A.stride = stride; A.bpos = d_bpos; A.offsets = d_offsets; A.nentered = d_nentered;
+	A.cum = c->d_parse_ws; A.centry = A.cum + n_frames + 1; A.summ = A.centry + maxchunks;
+	A.n_frames = n_frames; A.nblk = nblk;
+	uint32_t grid = (uint32_t)(maxchunks < (size_t)c->n_cu * 8 ? maxchunks : (size_t)c->n_cu * 8);
+	hipLaunchKernelGGL(k_parse_prefix, dim3(1), dim3(64), 0, s, A);
+	CK(hipGetLastError());
+	if (c->mode512) hipLaunchKernelGGL(k_parse_chunks<true>, dim3(grid), dim3(PT), 0, s, A);
+	else            hipLaunchKernelGGL(k_parse_chunks<false>, dim3(grid), dim3(PT), 0, s, A);
+	CK(hipGetLastError());
+	hipLaunchKernelGGL(k_parse_stitch, dim3(n_frames), dim3(64), 0, s, A);
+	CK(hipGetLastError());
+	if (c->mode512) hipLaunchKernelGGL(k_parse_emit<true>, dim3(grid), dim3(PT), 0, s, A);
+	else            hipLaunchKernelGGL(k_parse_emit<false>, dim3(grid), dim3(PT), 0, s, A);
 	CK(hipGetLastError());
 	return 0;
 }
@@ -1011,7 +1429,7 @@ extern "C" int agmv_hip_decode_frames_dev(agmv_hip_ctx* c, const uint8_t* d_bits
 	A.tpf = (A.nblk + DEC_T - 1) / DEC_T;
 	A.first_fc = first_fc; A.phase = first_fc & 3u;
 	A.n_groups = (n_frames + A.phase + 3) / 4;
-	size_t nwords = (A.nblk + 31) / 32;
+	size_t nwords = (A.nblk + 31) / 32 + 1;                    // bitmap + the "anything to repair" word
 	if (nwords > c->dirty_cap) {
 		if (c->d_dirty) CK(hipFree(c->d_dirty));
 		c->d_dirty = nullptr; c->dirty_cap = 0;

@@ -1,0 +1,282 @@
+/*
+ * libagmv_amd/csrc/agmv_lz.c -- the host entropy stage: LZSS / LZ77 as the reference defines
+ * them (reference src/agmv_encode.c:106-238 encoders, src/agmv_decode.c:171-218 decoders),
+ * bit-exact but not brute force.
+ *
+ * The reference scans the whole 65535-byte window for every token (O(n * 65535): 16 s per noisy
+ * 1080p frame).  What it computes is well defined: the LONGEST match (capped at 15 for LZSS, 255
+ * for LZ77) whose start lies in [i-65535, i), and among equally long ones the EARLIEST start
+ * (strict '>' while scanning oldest -> newest, src/agmv_encode.c:138).  Here:
+ *   LZSS  for every length L = 3..15 a hash of L-grams whose buckets are FIFO queues of window
+ *         positions; the first L (from 15 down) that has a verified hit is the match length and
+ *         the queue front is the earliest start.  O(13) per byte.
+ *   LZ77  lengths 1..2 by the same queues, longer ones by a full walk of the 3-gram chain.
+ * State is per call (the reference's is file-static), so frames compress on several host
+ * threads; the FILE* entry points AGMV_LZSS/AGMV_LZ77 feed the shared AGMV_WriteBits like the
+ * reference does.
+ */
+#include <stdlib.h>
+#include <string.h>
+
+#include "agmv.h"
+#include "agmv_internal.h"
+
+#define WIN 65535
+#define RING 65536
+#define HBITS 16
+#define HSIZE (1u << HBITS)
+
+/* ---- FIFO buckets of window positions for one gram length ---------------------------------- */
+typedef struct gq {
+	int L;
+	int* head;          /* [HSIZE] oldest live position + 1, 0 = empty */
+	int* tail;          /* [HSIZE] newest */
+	int* nxt;           /* [RING]  next newer position + 1 in the same bucket */
+	unsigned short* bkt;/* [RING]  bucket of the position stored in the slot */
+} gq;
+
+static void gq_init(gq* q, int L)
+{
+	q->L = L;
+	q->head = (int*)calloc(HSIZE, sizeof(int));
+	q->tail = (int*)calloc(HSIZE, sizeof(int));
+	q->nxt = (int*)calloc(RING, sizeof(int));
+	q->bkt = (unsigned short*)calloc(RING, sizeof(unsigned short));
+}
+
+static void gq_free(gq* q) { free(q->head); free(q->tail); free(q->nxt); free(q->bkt); }
+
+static inline unsigned gram_hash(const u8* p, int L)
+{
+	unsigned h = 2166136261u;
+	int k;
+	for (k = 0; k < L; k++) h = (h ^ p[k]) * 16777619u;
+	return (h ^ (h >> 15)) & (HSIZE - 1);
+}
+
+/* insert position p (its L-gram must lie inside the data); evicts position p-RING first */
+static inline void gq_insert(gq* q, const u8* d, int p, int have_old)
+{
+	unsigned slot = (unsigned)p & (RING - 1), h;
+	if (have_old) {                              /* slot still holds p-RING: it is the head of its bucket */
+		unsigned ob = q->bkt[slot];
+		if (q->head[ob] == p - RING + 1) {
+			q->head[ob] = q->nxt[slot];
+			if (!q->head[ob]) q->tail[ob] = 0;
+		}
+	}
+	h = gram_hash(d + p, q->L);
+	q->bkt[slot] = (unsigned short)h;
+	q->nxt[slot] = 0;
+	if (q->tail[h]) q->nxt[(unsigned)(q->tail[h] - 1) & (RING - 1)] = p + 1;
+	else q->head[h] = p + 1;
+	q->tail[h] = p + 1;
+}
+
+/* earliest live position >= lo whose L-gram equals the one at i, or -1 */
+static inline int gq_find(const gq* q, const u8* d, int i, int lo)
+{
+	unsigned h = gram_hash(d + i, q->L);
+	int c = q->head[h];
+	while (c) {
+		int p = c - 1;
+		if (p >= lo && memcmp(d + p, d + i, (size_t)q->L) == 0) return p;
+		c = q->nxt[(unsigned)p & (RING - 1)];
+	}
+	return -1;
+}
+
+/* ---- token sinks ----------------------------------------------------------------------------*/
+typedef struct sink {
+	FILE* f;            /* FILE* mode: through AGMV_WriteBits / AGMV_WriteByte */
+	u8* out;            /* memory mode */
+	size_t n;
+	unsigned long long buf;
+	unsigned bits;
+} sink;
+
+static inline void put_bits(sink* s, unsigned v, unsigned nb)
+{
+	if (s->f) { AGMV_WriteBits(s->f, v, (u16)nb); return; }
+	s->buf |= (unsigned long long)v << s->bits;
+	s->bits += nb;
+	while (s->bits >= 8) { s->out[s->n++] = (u8)s->buf; s->buf >>= 8; s->bits -= 8; }
+}
+
+static inline void put_byte(sink* s, unsigned v)
+{
+	if (s->f) AGMV_WriteByte(s->f, (u8)v);
+	else s->out[s->n++] = (u8)v;
+}
+
+/* ---- LZSS (reference src/agmv_encode.c:106-177) ---------------------------------------------*/
+static u32 lzss_run(const u8* d, int n, sink* s)
+{
+	gq q[16];
+	int L, i = 0, ins = 0, outbits = 0;
+	for (L = 3; L <= 15; L++) gq_init(&q[L], L);
+	while (i < n) {
+		int maxlen = n - i < 15 ? n - i : 15, lo = i - WIN, best = 0, start = 0;
+		if (lo < 0) lo = 0;
+		/* make every position < i that owns an L-gram visible */
+		for (; ins < i; ins++)
+			for (L = 3; L <= 15; L++)
+				if (ins + L <= n) gq_insert(&q[L], d, ins, ins >= RING);
+		for (L = maxlen; L >= 3; L--) {
+			int p = gq_find(&q[L], d, i, lo);
+			if (p >= 0) { best = L; start = p; break; }
+		}
+		if (best < 3) {                                    /* literal: flag 1 + 8 bits */
+			put_bits(s, 1, 1); put_bits(s, d[i], 8);
+			outbits += 9; i += 1;
+		} else {                                           /* match: flag 0 + 16-bit distance + 4-bit length */
+			put_bits(s, 0, 1); put_bits(s, (unsigned)(i - start), 16); put_bits(s, (unsigned)best, 4);
+			outbits += 21; i += best;
+		}
+	}
+	for (L = 3; L <= 15; L++) gq_free(&q[L]);
+	return (u32)((float)outbits / 8.0f);                   /* csize is computed in float, :176 */
+}
+
+/* ---- LZ77 (reference src/agmv_encode.c:179-238): 4-byte tokens {u16 distance, u8 length, u8 next}.
+ * d must have n+1 readable bytes: a match that runs to the end emits d[n] as `next` (:222). */
+static u32 lz77_run(const u8* d, int n, sink* s)
+{
+	gq q1, q2;
+	int *chead, *cprev;                                    /* 3-gram chains, newest first */
+	int i = 0, ins = 0, outbits = 0;
+	gq_init(&q1, 1); gq_init(&q2, 2);
+	chead = (int*)calloc(HSIZE, sizeof(int));
+	cprev = (int*)calloc(RING, sizeof(int));
+	while (i < n) {
+		int maxlen = n - i < 255 ? n - i : 255, lo = i - WIN, best = 0, start = 0;
+		if (lo < 0) lo = 0;
+		for (; ins < i; ins++) {
+			gq_insert(&q1, d, ins, ins >= RING);
+			if (ins + 2 <= n) gq_insert(&q2, d, ins, ins >= RING);
+			if (ins + 3 <= n) {
+				unsigned h = gram_hash(d + ins, 3);
+				cprev[(unsigned)ins & (RING - 1)] = chead[h];
+				chead[h] = ins + 1;
+			}
+		}
+		if (maxlen >= 3) {                                 /* longest >= 3, earliest among equals */
+			int c = chead[gram_hash(d + i, 3)];
+			while (c) {
+				int p = c - 1, j;
+				if (p < lo) break;                         /* chain is ordered newest -> oldest */
+				for (j = 0; j < maxlen && d[p + j] == d[i + j]; j++) {}
+				if (j >= 3 && j >= best) { best = j; start = p; }
+				c = cprev[(unsigned)p & (RING - 1)];
+				if (c && c - 1 >= p) break;                /* slot was recycled: chain left the window */
+			}
+		}
+		if (best < 3 && maxlen >= 2) { int p = gq_find(&q2, d, i, lo); if (p >= 0) { best = 2; start = p; } }
+		if (best < 2 && maxlen >= 1) { int p = gq_find(&q1, d, i, lo); if (p >= 0) { best = 1; start = p; } }
+		if (best > 0) {
+			unsigned dist = (unsigned)(i - start);
+			put_byte(s, dist & 0xff); put_byte(s, dist >> 8); put_byte(s, (unsigned)best); put_byte(s, d[i + best]);
+			i += best + 1;
+		} else {
+			put_byte(s, 0); put_byte(s, 0); put_byte(s, 0); put_byte(s, d[i]);
+			i += 1;
+		}
+		outbits += 32;
+	}
+	gq_free(&q1); gq_free(&q2); free(chead); free(cprev);
+	return (u32)((float)outbits / 8.0f);
+}
+
+/* ---- API -----------------------------------------------------------------------------------*/
+u32 AGMV_LZSS(FILE* file, AGMV_BITSTREAM* in)
+{
+	sink s;
+	memset(&s, 0, sizeof(s));
+	s.f = file;
+	return lzss_run(in->data, (int)in->pos, &s);
+}
+
+u32 AGMV_LZ77(FILE* file, AGMV_BITSTREAM* in)
+{
+	sink s;
+	memset(&s, 0, sizeof(s));
+	s.f = file;
+	return lz77_run(in->data, (int)in->pos, &s);
+}
+
+/* memory forms used by the batch drivers: returns the bytes the reference leaves in the file for the
+   payload, i.e. exactly csize bytes (the flushed partial byte is overwritten by the 0xFF guard,
+   reference src/agmv_encode.c:579-585,622-624).  `out` needs 2*n+16 (LZSS) / 4*n+16 (LZ77) bytes. */
+u32 agmv_lzss_mem(const u8* in, size_t n, u8* out)
+{
+	sink s;
+	memset(&s, 0, sizeof(s));
+	s.out = out;
+	return lzss_run(in, (int)n, &s);
+}
+
+u32 agmv_lz77_mem(const u8* in, size_t n, u8* out)
+{
+	sink s;
+	memset(&s, 0, sizeof(s));
+	s.out = out;
+	return lz77_run(in, (int)n, &s);
+}
+
+/* ---- decoders from memory (reference src/agmv_decode.c:171-218).  `data` is the persistent
+ * decompression buffer (bytes beyond the new bpos keep their old content), `cap` its size.
+ * Returns bpos; *consumed = payload bytes read (the bit reader runs past csize into the guard). */
+typedef struct brd { const u8* p; size_t avail, pos; unsigned long long buf; unsigned bits; } brd;
+
+static inline unsigned rd_byte(brd* r) { return r->pos < r->avail ? r->p[r->pos++] : 0u; }
+
+static inline unsigned rd_bits(brd* r, unsigned nb)
+{
+	unsigned long long v = r->buf >> (8 - r->bits);
+	while (nb > r->bits) { r->buf = rd_byte(r); v |= r->buf << r->bits; r->bits += 8; }
+	r->bits -= nb;
+	return (unsigned)(v & ((1u << nb) - 1u));
+}
+
+u32 agmv_lz_decode_mem(int version, const u8* payload, size_t avail, u32 usize, u32 csize, u8* data, size_t cap,
+                       size_t* consumed)
+{
+	brd r;
+	unsigned long long bpos = 0, lim = cap > 16 ? cap - 16 : 0;
+	memset(&r, 0, sizeof(r));
+	r.p = payload; r.avail = avail;
+	if (version == 1 || version == 2) {
+		unsigned long long nbits = (unsigned long long)csize * 8, bits = 0;
+		while (bits < nbits && bpos < usize && bpos < lim) {
+			unsigned flag = rd_bits(&r, 1);
+			bits++;
+			if (flag & 1) { data[bpos++] = (u8)rd_bits(&r, 8); bits += 8; }
+			else {
+				unsigned offset = rd_bits(&r, 16), len = rd_bits(&r, 4), k;
+				unsigned long long pos = bpos;
+				bits += 20;
+				for (k = 0; k < len; k++) {
+					unsigned long long src = pos - offset + k;         /* wraps like the reference's u32 */
+					if (src < bpos && bpos < lim) data[bpos++] = data[src];
+				}
+			}
+		}
+	} else {
+		u32 t;
+		for (t = 0; t < csize; t += 4) {
+			unsigned offset = rd_byte(&r), len, k;
+			u8 byte;
+			unsigned long long pos = bpos;
+			offset |= rd_byte(&r) << 8;
+			len = rd_byte(&r);
+			byte = (u8)rd_byte(&r);
+			for (k = 0; k < len; k++) {
+				unsigned long long src = pos - offset + k;
+				if (src < bpos && bpos < lim) data[bpos++] = data[src];
+			}
+			if (bpos < lim) data[bpos++] = byte;
+		}
+	}
+	if (consumed) *consumed = r.pos;
+	return (u32)bpos;
+}

@@ -28,7 +28,8 @@ class HipUnavailable(RuntimeError):
 
 
 def lib_path():
-    return os.path.join(HERE, "libagmv_hip.so")
+    # AGMV_HIP_LIB: tools/ablate.sh points the probe at instrumented builds of the same source
+    return os.environ.get("AGMV_HIP_LIB") or os.path.join(HERE, "libagmv_hip.so")
 
 
 _lib = None

@@ -287,6 +287,39 @@ def test_decode_truncated_and_garbage_streams(torch, hip):
             assert (got[t] == exp[t]).all(), "mode512=%s frame %d" % (mode512, t)
 
 
+def test_parallel_parser_matches_serial_walk(torch, hip, monkeypatch):
+    """the chunked pointer-doubling parser (k_parse_chunks/stitch/emit) against the one-lane-per-frame
+    walk (k_parse_serial) on streams the CPU oracle is too slow for: 1080p clips (COPY-heavy P-frames =
+    1-byte nodes, FILL, NORMAL with escapes), pure noise bytes (constant flag resync), and truncations."""
+    W, H, T = 1920, 1080, 8
+    nblk = W * H // 16
+    frames = hip.synth_dev(W, H, 0, T)
+    noise = torch.randint(0, 1 << 24, (2, H, W), dtype=torch.int32, device="cuda")
+    frames = torch.cat([frames, noise])
+    T += 2
+    for mode512 in (True, False):
+        p0, p1 = S.content_palettes([S.synth_frame(W, H, 0)])
+        hip.set_palette(p0, p1, mode512)
+        out, sizes = hip.encode_dev(frames, T, W, H)
+        hip.check()
+        # add two garbage "streams" and truncate two real ones
+        out = torch.cat([out, torch.randint(0, 256, (2, out.shape[1]), dtype=torch.uint8, device="cuda")])
+        sizes = torch.cat([sizes, torch.tensor([300000, 5], dtype=torch.int32, device="cuda")])
+        sizes[1] = sizes[1] - 7
+        sizes[2] = 1000
+        n = T + 2
+        monkeypatch.setenv("AGMV_HIP_PARSE", "serial")
+        o_ser, n_ser = hip.parse_dev(out, sizes, n, W, H)
+        torch.cuda.synchronize()
+        monkeypatch.delenv("AGMV_HIP_PARSE")
+        o_par, n_par = hip.parse_dev(out, sizes, n, W, H)
+        torch.cuda.synchronize()
+        assert torch.equal(n_ser, n_par), (n_ser.cpu().numpy(), n_par.cpu().numpy())
+        ne = n_ser.cpu().numpy()
+        for f in range(n):
+            assert torch.equal(o_ser[f, :ne[f]], o_par[f, :ne[f]]), "mode512=%s frame %d (nentered %d of %d)" % (mode512, f, ne[f], nblk)
+
+
 # ------------------------------------------------------------------------------- helpers
 def test_synth_interp_histogram(torch, hip):
     for (W, H) in ((320, 240), (68, 36)):

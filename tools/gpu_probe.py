@@ -47,12 +47,16 @@ print("encode: %.3f ms  (%s) -> %.1f frames/s, %.1f GB/s algorithmic (%.1f%% of 
 nblk = W * H // 16
 offs = torch.empty((T, nblk), dtype=torch.int32, device="cuda")
 nent = torch.empty(T, dtype=torch.int32, device="cuda")
-ms_p, ts = timed(lambda: hip.parse_dev(out, sizes, T, W, H, offsets=offs, nentered=nent), n=2, warm=1)
+ms_p, ts = timed(lambda: hip.parse_dev(out, sizes, T, W, H, offsets=offs, nentered=nent), n=5, warm=1)
 print("parse: %.3f ms" % ms_p)
 dec = torch.empty((T, H, W), dtype=torch.int32, device="cuda")
 ms_d, ts = timed(lambda: hip.decode_dev(out, sizes, offs, nent, T, W, H, out=dec))
 print("decode: %.3f ms (%s) -> %.1f frames/s, %.1f GB/s algorithmic (%.1f%% of 8 TB/s)"
       % (ms_d, ["%.2f" % t for t in ts], T / ms_d * 1e3, alg / ms_d / 1e6, alg / ms_d / 1e6 / 80))
+ms_f, _ = timed(lambda: dec.fill_(7))
+print("torch fill of the clip (4 B/px write only): %.3f ms -> %.1f GB/s" % (ms_f, 4 * W * H * T / ms_f / 1e6))
+ms_r, _ = timed(lambda: frames.sum())
+print("torch sum of the clip (4 B/px read only): %.3f ms -> %.1f GB/s" % (ms_r, 4 * W * H * T / ms_r / 1e6))
 # plain copy of the same pixel volume for reference
 ms_c, _ = timed(lambda: dec.copy_(frames))
 print("torch copy of the clip (4 B/px read + 4 B/px write): %.3f ms -> %.1f GB/s" % (ms_c, 8 * W * H * T / ms_c / 1e6))
