@@ -257,99 +257,100 @@ __device__ __forceinline__ void copy_out(const uint8_t* stage, uint8_t* gdst, ui
 	}
 }
 
-constexpr int WBLK = 64;                                       // blocks per wave-tile
-constexpr int WSTAGE = 4 + WBLK * 33 + 12;                     // front pad + worst case + tail pad (2128 B)
-static_assert(WSTAGE % 16 == 0, "stage buffers must stay 16-byte aligned");
-static_assert(WSTAGE >= WBLK * 16 * 2, "the entry transpose buffer aliases a stage buffer");
+constexpr int WBLK = 64;                                       // blocks per wave = slice of the workgroup tile
+constexpr int WSLICE = WBLK * 33;                              // stage bytes a wave's blocks can produce (2112)
+constexpr int STAGE_SZ = 4 + ENC_T * 33 + 12;                  // front pad + worst case + tail pad
+static_assert(STAGE_SZ % 16 == 0 && WSLICE % 16 == 0, "stage buffers / slices must stay 16-byte aligned");
+static_assert(WSLICE >= WBLK * 16 * 2 + 16, "the entry transpose scratch aliases the wave's stage slice");
+constexpr size_t CTRL_BYTES = 16;                              // [0] ticket, [1] error
 
-// wave-wide copy of `total` staged bytes to the frame bitstream (see copy_out above for the scheme)
-__device__ __forceinline__ void wave_copy_out(const uint8_t* stage, uint8_t* gdst, uint32_t total, int lane)
+// copy staged bytes [lo, hi) of a tile to the frame bitstream (gdst = address of staged byte 0), one wave:
+// dword stores on global-aligned dwords (staged byte i lives at stage byte 4+i), bytes at the ragged ends.
+__device__ __forceinline__ void wave_copy_out(const uint8_t* stage, uint8_t* gdst, uint32_t lo, uint32_t hi, int lane)
 {
-	const uint32_t s = (uint32_t)((uintptr_t)gdst & 3u);
-	uint8_t* g0 = gdst - s;
+	if (lo >= hi) return;
+	uint8_t* g = gdst + lo;
+	const uint32_t total = hi - lo;
+	const uint32_t s = (uint32_t)((uintptr_t)g & 3u);
+	uint8_t* g0 = g - s;
 	const uint32_t ndw = (s + total + 3u) >> 2;
-	const uint32_t* s32 = (const uint32_t*)stage;
+	const uint32_t* s32 = (const uint32_t*)(stage + lo);      // lo is a multiple of 4
 	for (uint32_t j = lane; j < ndw; j += 64) {
 		const int lo_i = (int)(4u * j) - (int)s;
 		if (lo_i >= 0 && (uint32_t)lo_i + 4u <= total) {
-			const uint32_t lo = s32[j], hi = s32[j + 1];
-			*(uint32_t*)(g0 + 4u * j) = s ? __builtin_amdgcn_alignbyte(hi, lo, 4u - s) : hi;
+			const uint32_t a = s32[j], b = s32[j + 1];
+			*(uint32_t*)(g0 + 4u * j) = s ? __builtin_amdgcn_alignbyte(b, a, 4u - s) : b;
 		} else {
 #pragma unroll
 			for (int q = 0; q < 4; q++) {
 				const int i = lo_i + q;
-				if (i >= 0 && (uint32_t)i < total) g0[4u * j + q] = stage[4 + i];
+				if (i >= 0 && (uint32_t)i < total) g0[4u * j + q] = stage[4 + lo + i];
 			}
 		}
 	}
 }
 
-// K1.  One WAVE = one tile of 64 consecutive 4x4 blocks, carried through the <=4 frames of one
-// GOP; the 8 waves of a workgroup only share the LDS bit matrix and run without any workgroup
-// barrier.  Per frame a wave
-//   (Q) quantises with lane = PIXEL: instruction g covers the 16x4-pixel patch of blocks 4g..4g+3,
-//       so the 64 addresses of one LUT gather fall into a handful of 4x4x4 colour cubes (lines);
-//       the entries are transposed to lane = BLOCK through LDS;
-//   (C) classifies its block (FILL / COPY / NORMAL) with one matrix bit per pixel and scans the
-//       block lengths across the wave;
-//   (E) emits the block's bytes into its LDS stage, publishes the tile aggregate, and
-//   (L) one frame later resolves the decoupled look-back of that frame (window prefetched a
-//       frame earlier) and copies the stage to the frame's bitstream.
+// K1.  One workgroup = one tile of 512 consecutive 4x4 blocks (8 waves x 64 blocks), carried through the
+// <=4 frames of one GOP; one lane owns one block for classification/emission.  Software-pipelined by one frame:
+//   iteration f:  (Q) quantise with lane = (block, row): wide row loads, each LUT gather instruction covers a
+//                     64x4-pixel patch (few 4x4x4 colour-cube lines); entries are transposed to lane = block
+//                     through the wave's own slice of stage[f&1] (no workgroup barrier needed)
+//                 (C) classify: FILL / COPY / NORMAL from one bit-matrix bit per pixel; wave scan of lengths
+//                 barrier; publish the tile aggregate of frame f; (E) emit bytes into stage[f&1]
+//                 (L) wave 0 resolves the decoupled look-back of frame f-1 (its status window was prefetched
+//                     before the compute); barrier; every wave copies its slice of stage[(f-1)&1] out.
 template <bool M512>
 __global__ __launch_bounds__(ENC_T, 4) void k_encode(EncArgs A)
 {
 	constexpr int NROWS = M512 ? 512 : 256;
 	extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
 	uint32_t* s_mtx = (uint32_t*)smem;                         // NROWS * MROW dwords
+	uint8_t* s_stage0 = smem + NROWS * MROW * 4;               // two stage buffers
+	uint32_t* s_misc = (uint32_t*)(s_stage0 + 2 * STAGE_SZ);   // [0..15] wave sums x2, [16..17] base x2, [18] ticket
+
 	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-	uint8_t* s_wave = smem + NROWS * MROW * 4 + wave * (2 * WSTAGE);   // this wave's two stage buffers
 	const uint32_t npx = A.w * A.h;
-
-	for (int i = tid; i < NROWS * MROW; i += ENC_T) s_mtx[i] = A.mtx[i];
-	__syncthreads();                                           // the only workgroup barrier
-
 	const uint32_t jb = lane >> 2, prow = lane & 3;            // quantise phase: lane = (block jb of 16, row prow)
 	const __amdgpu_buffer_rsrc_t lut_rs = __builtin_amdgcn_make_buffer_rsrc((void*)A.lut, 0, (int)(LUT_ENTRIES * 2u), 0x00020000);
 
-	// tickets come in chunks of TCHUNK per atomic: one returning atomic word sustains only ~88 dequeues/us
-	// chip-wide (MI355X_MICROARCH "dequeue"), far fewer than the ~260 wave-tiles/us this kernel retires.
-	// Consecutive tickets are the same tile of DIFFERENT GOPs, so the tiles of a chunk never wait on each other.
-	constexpr uint32_t TCHUNK = 8;
-	uint32_t t = 0, t_end;
-	if (lane == 0) t = atomicAdd(A.ctrl, TCHUNK);
-	t = __builtin_amdgcn_readfirstlane(t);
-	t_end = t + TCHUNK;
-	uint32_t t_next = 0;
-	while (t < A.total_tiles) {
-		if (t + 1 == t_end && lane == 0) t_next = atomicAdd(A.ctrl, TCHUNK);   // next chunk: in flight during the last tile
-		// tile-major ticket order: consecutive tickets are the SAME tile of different GOPs, so a
-		// tile's predecessors (same GOP, lower tile) are n_groups tickets older -> mostly finished
-		// and already carrying an inclusive prefix when the look-back reads them.
+	for (int i = tid; i < NROWS * MROW; i += ENC_T) s_mtx[i] = A.mtx[i];
+
+	for (;;) {
+		__syncthreads();                                       // matrix ready / previous tile fully drained
+		if (tid == 0) s_misc[18] = atomicAdd(A.ctrl, 1u);
+		__syncthreads();
+		const uint32_t t = s_misc[18];
+		if (t >= A.total_tiles) break;
+		// tile-major ticket order: consecutive tickets are the SAME tile of different GOPs, so a tile's
+		// predecessors (same GOP, lower tile) are n_groups tickets older -> mostly finished and already
+		// carrying an inclusive prefix when the look-back reads them.
 		const uint32_t tile = t / A.n_groups, group = t - tile * A.n_groups;
 		const int f_lo = group == 0 ? 0 : (int)(group * 4 - A.phase);
 		int f_hi = (int)(group * 4 - A.phase) + 4;
 		if (f_hi > (int)A.n_frames) f_hi = (int)A.n_frames;
 
-		// lane-as-block geometry (classification, I-frame entry plane)
-		const uint32_t blk = tile * WBLK + lane;
+		// lane-as-block geometry (classification, emission, I-frame entry plane)
+		const uint32_t wbase = tile * ENC_T + wave * WBLK;      // first block of this wave
+		const uint32_t blk = wbase + lane;
 		const bool valid = blk < A.nblk;
 		const uint32_t bb = valid ? blk : A.nblk - 1;
 		const uint32_t by = bb / A.bw, bx = bb - by * A.bw;
 		const uint32_t poff = by * 4 * A.w + bx * 4;           // top-left pixel of the block
 
 		// quantise geometry, lane = (block, row): load i (0..3) fetches row `prow` (16 bytes) of block
-		// tile*64 + 16i + jb, so one instruction reads four 256-byte row segments of 16 adjacent blocks
+		// wbase + 16i + jb, so one instruction reads four 256-byte row segments of 16 adjacent blocks
 		// (1 KiB, full lines) and each of its four pixel columns is a 64x4-pixel patch for the LUT gather.
-		// Offsets are not kept in registers: a tile inside one block row uses immediate offsets, a tile
-		// crossing one row boundary adds 3*w past it, anything else (frames narrower than 64 blocks, the
-		// ragged last tile) walks the blocks incrementally.
-		const uint32_t B0 = tile * WBLK + jb;
+		// Offsets are not kept in registers: a wave inside one block row uses immediate offsets, one
+		// crossing a row boundary adds 3*w past it, anything else (frames narrower than 64 blocks, the
+		// ragged end of the frame) recomputes the block position.
+		const uint32_t B0 = wbase + jb;
 		const uint32_t Bc0 = B0 < A.nblk ? B0 : A.nblk - 1;
 		const uint32_t qy0 = Bc0 / A.bw, qx0 = Bc0 - qy0 * A.bw;
 		const uint32_t p0b = ((qy0 * 4 + prow) * A.w + qx0 * 4) * 4u, w3b = 12u * A.w;
-		const uint32_t row_first = (tile * WBLK) / A.bw, row_last = (tile * WBLK + WBLK - 1) / A.bw;
+		const uint32_t wb_c = wbase < A.nblk ? wbase : A.nblk - 1;
+		const uint32_t row_first = wb_c / A.bw, row_last = (wbase + WBLK - 1) / A.bw;
 		const uint32_t wrapB = (row_first + 1) * A.bw;          // first block of the next block row
-		const int path = (tile * WBLK + WBLK > A.nblk || row_last > row_first + 1) ? 2 : (row_last != row_first ? 1 : 0);
+		const int path = (wbase + WBLK > A.nblk || row_last > row_first + 1) ? 2 : (row_last != row_first ? 1 : 0);
 		auto load_frame = [&](const uint32_t* fp, uint4 (&dst)[4]) {
 			// uniform 128-bit descriptor per frame + one 32-bit byte offset per lane
 			const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)fp, 0, (int)(npx * 4u), 0x00020000);
@@ -362,7 +363,7 @@ __global__ __launch_bounds__(ENC_T, 4) void k_encode(EncArgs A)
 					dst[i] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rs, p0b + 256 * i + (B0 + 16 * i >= wrapB ? w3b : 0u), 0, 0));
 			} else {
 #pragma unroll
-				for (int i = 0; i < 4; i++) {                  // generic: recompute the block position (4 divisions per frame)
+				for (int i = 0; i < 4; i++) {
 					uint32_t B = B0 + 16 * i;
 					if (B >= A.nblk) B = A.nblk - 1;           // blocks past the frame re-read the last valid one
 					const uint32_t qy = B / A.bw, qx = B - qy * A.bw;
@@ -391,13 +392,15 @@ __global__ __launch_bounds__(ENC_T, 4) void k_encode(EncArgs A)
 		for (int f = f_lo; f <= f_hi; f++) {
 			const bool have_cur = f < f_hi, have_prev = f > f_lo;
 			unsigned long long pre = ST_PREFIX;
-			if (have_prev && tile != 0)                        // prefetch the look-back window of frame f-1
+#ifndef ABL_NOSTATUS
+			if (wave == 0 && have_prev && tile != 0)           // prefetch the look-back window of frame f-1
 				pre = st_load(A.status + (size_t)(f - 1) * A.tpf, (int)tile - 1 - lane);
-
+#endif
 			uint32_t total = 0;
 			if (have_cur) {
 				const bool is_i = ((A.first_fc + f) & 3u) == 0;
-				uint8_t* stage = s_wave + (f & 1) * WSTAGE;
+				uint8_t* stage = s_stage0 + (f & 1) * STAGE_SZ;
+				uint8_t* scratch = stage + 4 + wave * WSLICE;      // this wave's slice: free since its copy-out of f-2
 				// ---- (Q) colour -> entry through the exact table, lane = (block, row)
 				uint32_t eq[16];
 #pragma unroll
@@ -413,27 +416,25 @@ __global__ __launch_bounds__(ENC_T, 4) void k_encode(EncArgs A)
 #endif
 				}
 				if (f + 1 < f_hi) load_frame(A.pix + (size_t)(f + 1) * npx, px);   // prefetch the next frame of the GOP
-				// [block][pixel] u16 table, aliases the stage (dead until E); lane writes its row: 8 bytes at lane*8 + i*512
+				// [block][pixel] u16 table in the wave's scratch; a lane writes its row: 8 bytes at i*512 + lane*8
 #pragma unroll
 				for (int i = 0; i < 4; i++) {
 					uint2 q;
 					q.x = eq[i * 4 + 0] | (eq[i * 4 + 1] << 16);
 					q.y = eq[i * 4 + 2] | (eq[i * 4 + 3] << 16);
-					*(uint2*)(stage + i * 512 + lane * 8) = q;
+					*(uint2*)(scratch + 12 + i * 512 + lane * 8) = q;      // +12: 16-byte alignment of the b128 reads below
 				}
 				__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 				__builtin_amdgcn_wave_barrier();
 				// ---- transpose: lane = block reads its 16 entries (32 contiguous bytes)
 				uint32_t e[16];
 				{
-					const uint4 lo = *(const uint4*)(stage + lane * 32), hi = *(const uint4*)(stage + lane * 32 + 16);
+					const uint4 lo = *(const uint4*)(scratch + 12 + lane * 32), hi = *(const uint4*)(scratch + 12 + lane * 32 + 16);
 					e[0] = lo.x & 0xffffu; e[1] = lo.x >> 16; e[2] = lo.y & 0xffffu; e[3] = lo.y >> 16;
 					e[4] = lo.z & 0xffffu; e[5] = lo.z >> 16; e[6] = lo.w & 0xffffu; e[7] = lo.w >> 16;
 					e[8] = hi.x & 0xffffu; e[9] = hi.x >> 16; e[10] = hi.y & 0xffffu; e[11] = hi.y >> 16;
 					e[12] = hi.z & 0xffffu; e[13] = hi.z >> 16; e[14] = hi.w & 0xffffu; e[15] = hi.w >> 16;
 				}
-				__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-				__builtin_amdgcn_wave_barrier();
 				// ---- (C) block tests. count1 = CompareIFrameBlock vs the top-left entry colour
 				// (src/agmv_encode.c:302-352), count2 = ComparePFrameBlock vs the I-frame entries
 				// (src/agmv_encode.c:240-300); one matrix bit per pixel.
@@ -483,21 +484,31 @@ __global__ __launch_bounds__(ENC_T, 4) void k_encode(EncArgs A)
 					}
 				}
 
-				// ---- byte offsets inside the tile: wave scan; publish the tile aggregate
+				// ---- byte offsets inside the tile: wave scan -> workgroup scan
+				uint32_t* wsum = s_misc + (f & 1) * 8;
 				const uint32_t incl = wave_incl_scan(len, lane);
-				total = __shfl(incl, 63, 64);
-				if (lane == 0) {
+				if (lane == 63) wsum[wave] = incl;
+				__syncthreads();                                   // (A) every wave is done with its scratch slice
+				uint32_t woff = 0;
+#pragma unroll
+				for (int i = 0; i < ENC_WAVES; i++) {
+					uint32_t s = wsum[i];
+					if (i < wave) woff += s;
+					total += s;
+				}
+#ifndef ABL_NOSTATUS
+				if (tid == 0) {
 					unsigned long long v = (tile == 0 ? ST_PREFIX : ST_AGG) | total;
 					__hip_atomic_store(A.status + (size_t)f * A.tpf + tile, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 				}
-
+#endif
 				// ---- (E) emit this block's bytes into the LDS stage (independent of the global base)
 #ifdef ABL_NOEMIT
 				if (valid && len == 0xFFFFu) {
 #else
 				if (valid) {
 #endif
-					uint8_t* sp = stage + 4 + incl - len;
+					uint8_t* sp = stage + 4 + woff + incl - len;
 					if (copy) {
 						sp[0] = COPY_FLAG;
 					} else if (fill) {
@@ -525,15 +536,15 @@ __global__ __launch_bounds__(ENC_T, 4) void k_encode(EncArgs A)
 						}
 					}
 				}
-				__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-				__builtin_amdgcn_wave_barrier();
+			} else {
+				__syncthreads();                                   // keep the barrier sequence identical on the drain iteration
 			}
 
-			// ---- (L) resolve frame f-1: look-back, then copy its stage out
-			if (have_prev) {
+			// ---- (L) resolve frame f-1: look-back (wave 0), then copy its stage out
+			if (wave == 0 && have_prev) {
 				unsigned long long* st = A.status + (size_t)(f - 1) * A.tpf;
 				uint32_t excl = 0;
-#ifdef ABL_NOLOOKBACK
+#if defined(ABL_NOLOOKBACK) || defined(ABL_NOSTATUS)
 				if (false) {
 #else
 				if (tile != 0) {
@@ -543,17 +554,23 @@ __global__ __launch_bounds__(ENC_T, 4) void k_encode(EncArgs A)
 						__hip_atomic_store(st + tile, ST_PREFIX | (unsigned long long)(excl + total_prev),
 						                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 				}
-				if (lane == 0 && tile == A.tpf - 1) A.sizes[f - 1] = excl + total_prev;   // usize of the frame
+				if (lane == 0) {
+					s_misc[16 + ((f - 1) & 1)] = excl;
+					if (tile == A.tpf - 1) A.sizes[f - 1] = excl + total_prev;   // usize of the frame
+				}
+			}
+			__syncthreads();                                       // (B) stage[f&1] written, base of f-1 known
 #ifdef ABL_NOEMIT
-				if (total_prev == 0xFFFFFFFFu)
+			if (have_prev && total_prev == 0xFFFFFFFFu) {
+#else
+			if (have_prev) {
 #endif
-				wave_copy_out(s_wave + ((f - 1) & 1) * WSTAGE, A.out + (size_t)(f - 1) * A.out_stride + excl, total_prev, lane);
-				__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-				__builtin_amdgcn_wave_barrier();
+				const uint32_t base = s_misc[16 + ((f - 1) & 1)];
+				const uint32_t lo = wave * WSLICE, hi = lo + WSLICE < total_prev ? lo + WSLICE : total_prev;
+				wave_copy_out(s_stage0 + ((f - 1) & 1) * STAGE_SZ, A.out + (size_t)(f - 1) * A.out_stride + base, lo, hi, lane);
 			}
 			total_prev = total;
 		}
-		if (++t == t_end) { t = __builtin_amdgcn_readfirstlane(t_next); t_end = t + TCHUNK; }
 	}
 }
 
@@ -1205,7 +1222,7 @@ extern "C" agmv_hip_ctx* agmv_hip_create(int device)
 	CKP(hipMalloc(&c->d_lut, (size_t)LUT_ENTRIES * sizeof(uint16_t)));
 	CKP(hipMalloc(&c->d_mtx, 512 * MROW * sizeof(uint32_t)));
 	CKP(hipMalloc(&c->d_pal, 512 * sizeof(uint32_t)));
-	CKP(hipMalloc(&c->d_ctrl, 16));
+	CKP(hipMalloc(&c->d_ctrl, CTRL_BYTES));
 	hipDeviceProp_t prop;
 	CKP(hipGetDeviceProperties(&prop, device));
 	c->n_cu = prop.multiProcessorCount;
@@ -1288,7 +1305,7 @@ extern "C" int agmv_hip_encode_frames_dev(agmv_hip_ctx* c, const uint32_t* d_pix
 	A.pix = d_pix; A.out = d_out; A.sizes = d_sizes; A.lut = c->d_lut; A.mtx = c->d_mtx; A.ientries = d_ientries;
 	A.out_stride = out_stride;
 	A.n_frames = n_frames; A.w = w; A.h = h; A.bw = w / 4; A.nblk = (w / 4) * (h / 4);
-	A.tpf = (A.nblk + WBLK - 1) / WBLK;
+	A.tpf = (A.nblk + ENC_T - 1) / ENC_T;
 	A.first_fc = first_fc; A.phase = first_fc & 3u;
 	A.n_groups = (n_frames + A.phase + 3) / 4;
 	A.total_tiles = A.n_groups * A.tpf;
@@ -1308,10 +1325,10 @@ extern "C" int agmv_hip_encode_frames_dev(agmv_hip_ctx* c, const uint32_t* d_pix
 	}
 	A.status = c->d_status; A.ctrl = c->d_ctrl;
 	CK(hipMemsetAsync(c->d_status, 0, need * sizeof(unsigned long long), s));
-	CK(hipMemsetAsync(c->d_ctrl, 0, 16, s));
+	CK(hipMemsetAsync(c->d_ctrl, 0, CTRL_BYTES, s));
 	uint32_t grid = (uint32_t)c->enc_grid;
-	if (grid > (A.total_tiles + ENC_WAVES - 1) / ENC_WAVES) grid = (A.total_tiles + ENC_WAVES - 1) / ENC_WAVES;
-	const size_t lds = (size_t)(c->mode512 ? 512 : 256) * MROW * 4 + (size_t)ENC_WAVES * 2 * WSTAGE;
+	if (grid > A.total_tiles) grid = A.total_tiles;
+	const size_t lds = (size_t)(c->mode512 ? 512 : 256) * MROW * 4 + 2 * STAGE_SZ + 128;
 	if (c->mode512) {
 		CK(hipFuncSetAttribute((const void*)k_encode<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
 		hipLaunchKernelGGL(k_encode<true>, dim3(grid), dim3(ENC_T), lds, s, A);
