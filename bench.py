@@ -1,0 +1,271 @@
+#!/usr/bin/env python3
+"""bench.py -- the AGMV hot path on MI355X: frames/s encode+decode, and the HBM roofline of the
+dominant kernel, next to the reference CPU path timed on the same box.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c3|c2|c5] [--frames T]
+  N > 1:  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+              --master-port P bench.py --gpus N --steps K --warmup W
+
+One STEP = one pass of the hot path over one batch of synthetic input already resident in HBM:
+  encode  k_encode            loops A+B of AGMV_EncodeFrame for every frame of the clip
+  decode  parser + k_decode   AGMV_DecodeFrameChunk's parse + reconstruct for every frame
+(the LZSS stage, file I/O and the palette build are host work by design and are not in the step).
+
+Workload (BASELINE.json configs):
+  c3 (default)  1024-frame 1920x1080 agmv_synth_v1 clip per GPU, AGMV_HIGH_QUALITY palette, OPT_III
+                (512 colours) -- the configuration the roofline target is quoted on
+  c2            212 source frames 320x240 -> the 156 encoded frames of AGMV_EncodeAGMV/OPT_III (light PDIFS)
+  c5            1280x720 clip (use --frames; 8192 frames need ~70 GB of HBM per GPU)
+Multi-GPU is weak scaling: every rank encodes+decodes its own T-frame clip (frames r*T .. r*T+T-1 of one
+long clip); the only collectives are outside the timed region (the palette histogram all-reduce before,
+the gather of the per-frame bitstreams to rank 0 after).  value = N*T*K / max-over-ranks time.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0        # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="c3", choices=["c3", "c2", "c5"])
+    ap.add_argument("--frames", type=int, default=0, help="frames per GPU (default: the workload's)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-frames", type=int, default=0, help="frames of the CPU baseline sample")
+    return ap.parse_args()
+
+
+def workload(args):
+    if args.workload == "c3":
+        return dict(name="c3: 1024-frame 1920x1080 agmv_synth_v1, HIGH_QUALITY palette, OPT_III (512 colours)",
+                    W=1920, H=1080, T=args.frames or 1024, quality=1, pdifs=False)
+    if args.workload == "c5":
+        return dict(name="c5: 1280x720 agmv_synth_v1 stream, HIGH_QUALITY palette, OPT_III",
+                    W=1280, H=720, T=args.frames or 1024, quality=1, pdifs=False)
+    return dict(name="c2: 212-frame 320x240 agmv_synth_v1 -> 156 encoded frames (AGMV_EncodeAGMV light PDIFS), "
+                     "LOW_QUALITY palette, OPT_III", W=320, H=240, T=args.frames or 212, quality=3, pdifs=True)
+
+
+def host_lib():
+    from libagmv_amd import build
+    build.build()
+    L = C.CDLL(os.path.join(ROOT, "libagmv_amd", "libagmv.so"))
+    L.AGMV_BuildPalette.restype = None
+    L.AGMV_BuildPalette.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    return L
+
+
+def cpu_baseline(wl, p0, p1, frames_np, gpu_bits):
+    """the reference's own compiled loops (oracle/_ref, kind 'reference') or, where that build is absent, the
+    oracle restatement (kind 'port') on a bounded sample of the same clip, one host thread.  Also a free parity
+    check: the sample's bitstreams must equal what the GPU produced for those frames."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracles as O
+    W, H = wl["W"], wl["H"]
+    kind = "reference" if O.have_ref() else "port"
+    enc = (O.RefEncoder if kind == "reference" else O.OracleEncoder)(W, H, True, p0, p1)
+    dec = O.OracleDecoder(W, H, True, p0, p1)
+    t_enc = t_dec = 0.0
+    for k, f in enumerate(frames_np):
+        t0 = time.perf_counter()
+        b = enc.encode(f)
+        t1 = time.perf_counter()
+        dec.decode(b)
+        t2 = time.perf_counter()
+        t_enc += t1 - t0
+        t_dec += t2 - t1
+        if gpu_bits is not None and not (len(b) == len(gpu_bits[k]) and (b == gpu_bits[k]).all()):
+            raise SystemExit("bench: GPU bitstream of frame %d differs from the %s CPU path" % (k, kind))
+    n = len(frames_np)
+    return {"value": round(n / (t_enc + t_dec), 4), "unit": "frames/s", "cores": 1, "kind": kind,
+            "sample": "first %d encoded frames of the same clip (%dx%d): AGMV_FindNearestEntry per pixel + "
+                      "Assemble{I,P}FrameBitstream (%.2f s/frame) then parse+reconstruct (%.4f s/frame); "
+                      "LZSS excluded on both sides" % (n, W, H, t_enc / n, t_dec / n),
+            "host_cores_available": os.cpu_count()}
+
+
+def main():
+    args = parse_args()
+    import torch
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("bench: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    elif args.gpus > 1:
+        raise SystemExit("bench: for --gpus N > 1 launch with torch.distributed.run (see the docstring)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    from libagmv_amd import AgmvHip
+    hip = AgmvHip(local_rank)
+    wl = workload(args)
+    W, H, T = wl["W"], wl["H"], wl["T"]
+    npx = W * H
+
+    # ------------------------------------------------------------------ setup (untimed)
+    if wl["pdifs"]:
+        # AGMV_EncodeAGMV light schedule (reference src/agmv_encode.c:2727-2752): per 4 inputs i..i+3 encode
+        # f(i), midpoint(f(i+1), f(i+2)), f(i+3); stop when i+4 >= end.  212 inputs -> 156 encoded frames.
+        src = hip.synth_dev(W, H, rank * T + 1, T, device=dev)          # frames numbered 1..T like the BMP files
+        pick = []
+        i = 1
+        while i <= T:
+            pick += [(i, -1), (i + 1, i + 2), (i + 3, -1)]
+            i += 4
+            if i + 4 >= T:
+                break
+        frames = torch.empty((len(pick), H, W), dtype=torch.int32, device=dev)
+        for k, (a, b) in enumerate(pick):
+            frames[k] = src[a - 1] if b < 0 else hip.interp_dev(src[a - 1], src[b - 1])
+        hist_src = src
+    else:
+        frames = hip.synth_dev(W, H, rank * T, T, device=dev)
+        hist_src = frames
+    n_enc = frames.shape[0]
+    hist = hip.histogram_dev(hist_src.reshape(-1), wl["quality"])
+    if dist is not None:
+        dist.all_reduce(hist)                                   # one palette for the whole job (pass 1 over all frames)
+    torch.cuda.synchronize()
+    hist_np = hist.cpu().numpy().view(np.uint32)
+    p0 = np.zeros(256, np.uint64)
+    p1 = np.zeros(256, np.uint64)
+    host_lib().AGMV_BuildPalette(hist_np.ctypes.data, wl["quality"], 3, p0.ctypes.data, p1.ctypes.data)   # OPT_III
+    p0 = p0.astype(np.uint32)
+    p1 = p1.astype(np.uint32)
+    hip.set_palette(p0, p1, True)
+    hip.enable_timing(True)
+
+    stride = hip.max_usize(W, H)
+    out = torch.empty((n_enc, stride), dtype=torch.uint8, device=dev)
+    sizes = torch.empty(n_enc, dtype=torch.int32, device=dev)
+    nblk = npx // 16
+    offs = torch.empty((n_enc, nblk), dtype=torch.int32, device=dev)
+    nent = torch.empty(n_enc, dtype=torch.int32, device=dev)
+    dec = torch.empty((n_enc, H, W), dtype=torch.int32, device=dev)
+
+    def step():
+        hip.encode_dev(frames, n_enc, W, H, 0, out=out, sizes=sizes)
+        hip.parse_dev(out, sizes, n_enc, W, H, offsets=offs, nentered=nent)
+        hip.decode_dev(out, sizes, offs, nent, n_enc, W, H, 0, out=dec)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    hip.check()
+
+    # ------------------------------------------------------------------ timed region: exactly K steps
+    k_ms = {"encode": [], "parse": [], "decode": []}
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+        # per-kernel durations from the HIP events the library recorded on this stream (reading them waits for the
+        # step's last kernel, which the next step depends on anyway)
+        for i, k in enumerate(("encode", "parse", "decode")):
+            k_ms[k].append(hip.last_kernel_ms(i))
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    hip.check()
+
+    # ------------------------------------------------------------------ results
+    usz = sizes.cpu().numpy().astype(np.int64)
+    assert (nent.cpu().numpy() == nblk).all(), "decoder did not reach every block of a clean stream"
+    alg_bytes = 4 * npx * n_enc + int(usz.sum())               # 4*W*H + usize per frame (same for decode)
+    enc_ms = float(np.mean(k_ms["encode"]))
+    par_ms = float(np.mean(k_ms["parse"]))
+    dec_ms = float(np.mean(k_ms["decode"]))
+    achieved = alg_bytes / (enc_ms * 1e-3) / 1e9
+
+    # final gather of the job's bitstreams to rank 0 (the only data collective; outside the timed region)
+    gather_ms = None
+    if dist is not None:
+        torch.cuda.synchronize()
+        g0 = time.perf_counter()
+        from libagmv_amd import shard
+        gathered = shard.gather_bitstreams(dist, sizes, shard.pack_frames(out, sizes), dst=0)
+        if rank == 0:
+            assert sum(int(s.numel()) for s, _ in gathered) == world * n_enc
+        torch.cuda.synchronize()
+        gather_ms = (time.perf_counter() - g0) * 1e3
+
+    if rank == 0:
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            try:
+                tj = json.load(open(tpath))
+                key = "%dx%dx%d" % (W, H, n_enc)
+                if key in tj.get("k_encode", {}):
+                    traffic = tj["k_encode"][key]
+            except Exception:
+                traffic = None
+        res = {
+            "metric": "frames/s encode+decode (AGMV hot path: quantise+classify+assemble, parse+reconstruct), synthetic",
+            "value": round(world * n_enc * args.steps / elapsed, 2),
+            "unit": "frames/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u8",
+            "data": "synthetic",
+            "config": {"workload": wl["name"], "frames_per_gpu": int(n_enc), "width": W, "height": H,
+                       "palette": "512 colours, reference histogram build (GPU histogram + host pick)",
+                       "parallelism": "frames sharded by GOP range, %d rank(s), no data-path collective" % world,
+                       "mean_usize_bytes": float(usz.mean())},
+            "roofline": {"bound": "hbm", "kernel": "k_encode", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": round(enc_ms, 4)},
+            "kernels_ms": {"k_encode": round(enc_ms, 4), "k_parse_*": round(par_ms, 4), "k_decode+k_fixup": round(dec_ms, 4)},
+            "decode_roofline": {"achieved": round(alg_bytes / (dec_ms * 1e-3) / 1e9, 1),
+                                "frac": round(alg_bytes / (dec_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                "with_parser_frac": round(alg_bytes / ((dec_ms + par_ms) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
+        }
+        if gather_ms is not None:
+            res["final_gather_ms"] = round(gather_ms, 3)
+        if world == 1 and not args.no_cpu_baseline:
+            n_cpu = args.cpu_frames or (8 if npx > 500000 else 32)
+            n_cpu = min(n_cpu, n_enc)
+            f_np = frames[:n_cpu].cpu().numpy().view(np.uint32)
+            gpu_bits = [out[f, :int(usz[f])].cpu().numpy() for f in range(n_cpu)]
+            res["cpu_baseline"] = cpu_baseline(wl, p0, p1, list(f_np), gpu_bits)
+        print(json.dumps(res))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    hip.close()
+
+
+if __name__ == "__main__":
+    main()

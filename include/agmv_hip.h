@@ -118,6 +118,12 @@ int agmv_hip_interp_dev(agmv_hip_ctx* ctx, uint32_t* d_out, const uint32_t* d_f1
 int agmv_hip_histogram_dev(agmv_hip_ctx* ctx, const uint32_t* d_pix, size_t n_pixels, int quality,
                            uint32_t* d_hist, void* stream);
 
+/* optional timing: when enabled the library records HIP events on the caller's stream around its three kernel
+   groups; agmv_hip_last_kernel_ms(which) returns the last launch's duration in ms (0 = k_encode, 1 = the parser
+   kernels, 2 = k_decode + k_fixup), or a negative value if unavailable */
+int   agmv_hip_enable_timing(agmv_hip_ctx* ctx, int on);
+float agmv_hip_last_kernel_ms(agmv_hip_ctx* ctx, int which);
+
 /* check for an asynchronous device-side failure (look-back timeout) after synchronising */
 int agmv_hip_check(agmv_hip_ctx* ctx, void* stream);
 

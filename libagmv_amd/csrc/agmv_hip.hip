@@ -73,6 +73,8 @@ struct agmv_hip_ctx {
 	int enc_grid;                   // resident workgroups for the persistent encode kernel
 	int n_cu;
 	uint32_t* d_parse_ws;           // parser workspace: cum | centry | summ
+	int timing;                     // record HIP events around the three hot kernels
+	hipEvent_t ev[6];               // encode, parse, decode: start/stop
 	size_t parse_ws_cap;            // in dwords
 };
 
@@ -1239,6 +1241,31 @@ extern "C" void agmv_hip_destroy(agmv_hip_ctx* c)
 	free(c);
 }
 
+static void ev_mark(agmv_hip_ctx* c, int which, hipStream_t s)
+{
+	if (c->timing) (void)hipEventRecord(c->ev[which], s);
+}
+
+extern "C" int agmv_hip_enable_timing(agmv_hip_ctx* c, int on)
+{
+	if (!c) return -1;
+	CK(hipSetDevice(c->device));
+	if (on && !c->ev[0]) for (int i = 0; i < 6; i++) CK(hipEventCreate(&c->ev[i]));
+	c->timing = on ? 1 : 0;
+	return 0;
+}
+
+/* duration in ms of the last launch of kernel group `which` (0 = k_encode, 1 = the parser kernels,
+   2 = k_decode + k_fixup), measured with HIP events on the stream it ran on; synchronises on the stop event */
+extern "C" float agmv_hip_last_kernel_ms(agmv_hip_ctx* c, int which)
+{
+	float ms = -1.0f;
+	if (!c || !c->timing || which < 0 || which > 2) return -1.0f;
+	if (hipEventSynchronize(c->ev[2 * which + 1]) != hipSuccess) return -1.0f;
+	if (hipEventElapsedTime(&ms, c->ev[2 * which], c->ev[2 * which + 1]) != hipSuccess) return -1.0f;
+	return ms;
+}
+
 static int need_ctx(agmv_hip_ctx* c, bool palette)
 {
 	if (!c) { snprintf(g_err, sizeof(g_err), "agmv_hip: NULL context"); return -1; }
@@ -1329,13 +1356,12 @@ extern "C" int agmv_hip_encode_frames_dev(agmv_hip_ctx* c, const uint32_t* d_pix
 	uint32_t grid = (uint32_t)c->enc_grid;
 	if (grid > A.total_tiles) grid = A.total_tiles;
 	const size_t lds = (size_t)(c->mode512 ? 512 : 256) * MROW * 4 + 2 * STAGE_SZ + 128;
-	if (c->mode512) {
-		CK(hipFuncSetAttribute((const void*)k_encode<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-		hipLaunchKernelGGL(k_encode<true>, dim3(grid), dim3(ENC_T), lds, s, A);
-	} else {
-		CK(hipFuncSetAttribute((const void*)k_encode<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-		hipLaunchKernelGGL(k_encode<false>, dim3(grid), dim3(ENC_T), lds, s, A);
-	}
+	if (c->mode512) CK(hipFuncSetAttribute((const void*)k_encode<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+	else CK(hipFuncSetAttribute((const void*)k_encode<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+	ev_mark(c, 0, s);
+	if (c->mode512) hipLaunchKernelGGL(k_encode<true>, dim3(grid), dim3(ENC_T), lds, s, A);
+	else hipLaunchKernelGGL(k_encode<false>, dim3(grid), dim3(ENC_T), lds, s, A);
+	ev_mark(c, 1, s);
 	CK(hipGetLastError());
 	return 0;
 }
@@ -1413,6 +1439,7 @@ extern "C" int agmv_hip_parse_frames_dev(agmv_hip_ctx* c, const uint8_t* d_bits,
 	A.cum = c->d_parse_ws; A.centry = A.cum + n_frames + 1; A.summ = A.centry + maxchunks;
 	A.n_frames = n_frames; A.nblk = nblk;
 	uint32_t grid = (uint32_t)(maxchunks < (size_t)c->n_cu * 8 ? maxchunks : (size_t)c->n_cu * 8);
+	ev_mark(c, 2, s);
 	hipLaunchKernelGGL(k_parse_prefix, dim3(1), dim3(64), 0, s, A);
 	CK(hipGetLastError());
 	if (c->mode512) hipLaunchKernelGGL(k_parse_chunks<true>, dim3(grid), dim3(PT), 0, s, A);
@@ -1423,6 +1450,7 @@ extern "C" int agmv_hip_parse_frames_dev(agmv_hip_ctx* c, const uint8_t* d_bits,
 	if (c->mode512) hipLaunchKernelGGL(k_parse_emit<true>, dim3(grid), dim3(PT), 0, s, A);
 	else            hipLaunchKernelGGL(k_parse_emit<false>, dim3(grid), dim3(PT), 0, s, A);
 	CK(hipGetLastError());
+	ev_mark(c, 3, s);
 	return 0;
 }
 
@@ -1455,6 +1483,7 @@ extern "C" int agmv_hip_decode_frames_dev(agmv_hip_ctx* c, const uint8_t* d_bits
 	}
 	A.dirty = c->d_dirty;
 	CK(hipMemsetAsync(c->d_dirty, 0, nwords * 4, s));
+	ev_mark(c, 4, s);
 	if (c->mode512) {
 		hipLaunchKernelGGL(k_decode<true>, dim3(A.n_groups * A.tpf), dim3(DEC_T), 0, s, A);
 		CK(hipGetLastError());
@@ -1465,6 +1494,7 @@ extern "C" int agmv_hip_decode_frames_dev(agmv_hip_ctx* c, const uint8_t* d_bits
 		hipLaunchKernelGGL(k_fixup<false>, dim3(1), dim3(64), 0, s, A);
 	}
 	CK(hipGetLastError());
+	ev_mark(c, 5, s);
 	return 0;
 }
 

@@ -19,7 +19,7 @@ ABI_SYMBOLS = [
     "agmv_hip_decode_frames_dev", "agmv_hip_decode_frames", "agmv_hip_synth_dev",
     "agmv_hip_interp_dev", "agmv_hip_histogram_dev", "agmv_hip_check", "agmv_hip_malloc",
     "agmv_hip_free", "agmv_hip_memcpy_h2d", "agmv_hip_memcpy_d2h", "agmv_hip_memset",
-    "agmv_hip_sync",
+    "agmv_hip_sync", "agmv_hip_enable_timing", "agmv_hip_last_kernel_ms",
 ]
 
 
@@ -67,6 +67,10 @@ def load_library():
     L.agmv_hip_interp_dev.argtypes = [vp, vp, vp, vp, sz, vp]
     L.agmv_hip_histogram_dev.argtypes = [vp, vp, sz, C.c_int, vp, vp]
     L.agmv_hip_check.argtypes = [vp, vp]
+    L.agmv_hip_enable_timing.argtypes = [vp, C.c_int]
+    L.agmv_hip_enable_timing.restype = C.c_int
+    L.agmv_hip_last_kernel_ms.argtypes = [vp, C.c_int]
+    L.agmv_hip_last_kernel_ms.restype = C.c_float
     L.agmv_hip_malloc.restype = vp
     L.agmv_hip_malloc.argtypes = [sz]
     L.agmv_hip_free.argtypes = [vp]
@@ -121,6 +125,12 @@ class AgmvHip:
         p1 = np.ascontiguousarray(p1, np.uint32) if p1 is not None else np.zeros(256, np.uint32)
         self.mode512 = bool(mode512)
         self._ck(self.L.agmv_hip_set_palette(self.ctx, _np_ptr(p0), _np_ptr(p1), int(mode512), self._stream()))
+
+    def enable_timing(self, on=True):
+        self._ck(self.L.agmv_hip_enable_timing(self.ctx, int(on)))
+
+    def last_kernel_ms(self, which):
+        return float(self.L.agmv_hip_last_kernel_ms(self.ctx, which))
 
     def check(self):
         self._ck(self.L.agmv_hip_check(self.ctx, self._stream()))
