@@ -685,20 +685,25 @@ __device__ __forceinline__ uint32_t find_frame(const uint32_t* cum, uint32_t n, 
 }
 
 // LDS layout shared by k_parse_chunks / k_parse_emit
+constexpr int PSEG = 64;                // positions per segment = one wave, chain doubling by shuffles
+constexpr int PNSEG = PC / PSEG;        // 16 segments per chunk
+constexpr uint32_t S_END = 0xFFu;       // segment tables: chain left the readable stream
+
 struct ParseLds {
 	uint8_t b[PC + PHALO];          // staged bytes
-	uint8_t ca[PC + PHALO];         // code-run lengths, ping
-	uint8_t cb[PC + PHALO];         // code-run lengths, pong
-	uint8_t d[PC];                  // bits 0..5 next(p)-p, bit 7 = node counts one block
-	uint16_t N[2][PC];              // blocks counted along the chain, ping-pong
+	uint8_t cw[PT / 64][4][2][128]; // per wave and segment slot: code-run lengths of a 128-byte window, ping/pong
+	uint8_t sE[PC];                 // per position: offset into the NEXT segment where its chain leaves this one (S_END: stream ended)
+	uint8_t sN[PC];                 // per position: blocks counted from it to the end of its segment
+	uint8_t dl[PC];                 // bits 0..5 next(p)-p, bit 7 = node counts one block
 };
 
-// builds d[] and the doubling levels J[0..PLV] (level i = position after 2^i nodes, >= PC once the
-// chain left the chunk, P_END once it left the stream).  With KEEP every level has its own table,
-// otherwise two tables ping-pong.  Returns the index (0/1) of the final N table.
+// Per chunk: node table (LDS, 4 barrier rounds for the 16-code run lengths), then per 64-position segment the
+// chain is resolved by pointer doubling IN REGISTERS: lane = position, 6 rounds of two shuffles (a node advances
+// >= 1 position, so 2^6 jumps leave the segment).  Because next(p)-p <= 33 < 64 a chain leaving segment s lands
+// inside segment s+1.  With KEEP the six jump levels are stored (as segment-relative bytes) for the marking pass.
 template <bool M512, bool KEEP>
-__device__ __forceinline__ int parse_chunk_tables(ParseLds& S, uint16_t (*J)[PC], const uint8_t* fbits, uint32_t cap,
-                                                  uint32_t bpos, uint32_t cs, int tid)
+__device__ __forceinline__ void parse_chunk_tables(ParseLds& S, uint8_t (*Jlv)[PC], const uint8_t* fbits, uint32_t cap,
+                                                   uint32_t bpos, uint32_t cs, int tid)
 {
 	// ---- stage the chunk (+halo), dword-wide (cs is a multiple of 1024, the slab 4-byte aligned)
 	for (int i = tid; i < (PC + PHALO) / 4; i += PT) {
@@ -711,74 +716,116 @@ __device__ __forceinline__ int parse_chunk_tables(ParseLds& S, uint16_t (*J)[PC]
 		((uint32_t*)S.b)[i] = v;
 	}
 	__syncthreads();
+	// ---- segments: wave w takes segments w, w+4, w+8, w+12.  Everything below is wave-local and the four
+	// segments are processed side by side (q = 0..3) so their LDS / shuffle round trips overlap.
+	const int lane = tid & 63, wave = tid >> 6;
+	constexpr int NQ = PNSEG / (PT / 64);                       // 4
+	const uint8_t* c16[NQ] = {nullptr, nullptr, nullptr, nullptr};
 	if (M512) {
-		// c1 -> c2 -> c4 -> c8 -> c16 : bytes taken by 1,2,4,8,16 consecutive entry codes
-		for (int i = tid; i < PC + PHALO; i += PT) S.ca[i] = (uint8_t)(1u + ((S.b[i] & 0x7fu) == 127u ? 1u : 0u));
-		__syncthreads();
-		uint8_t* src = S.ca;
-		uint8_t* dst = S.cb;
-		int lim = PC + PHALO;
+		// c1 -> c2 -> c4 -> c8 -> c16 : bytes taken by 1,2,4,8,16 consecutive entry codes, over the 128-byte window
+		// that starts at the segment (a NORMAL block at the last position needs c16 of the following byte)
+#pragma unroll
+		for (int q = 0; q < NQ; q++) {
+			const uint8_t* wb = S.b + (wave + q * (PT / 64)) * PSEG;
+			S.cw[wave][q][0][lane] = (uint8_t)(1u + ((wb[lane] & 0x7fu) == 127u ? 1u : 0u));
+			S.cw[wave][q][0][lane + 64] = (uint8_t)(1u + ((wb[lane + 64] & 0x7fu) == 127u ? 1u : 0u));
+		}
+		__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+		__builtin_amdgcn_wave_barrier();
+		int lim = 128;
 #pragma unroll
 		for (int r = 0; r < 4; r++) {
-			lim -= 2 << r;                                     // indices whose partner is still inside the staged range
-			for (int i = tid; i < lim; i += PT) { const uint32_t a = src[i]; dst[i] = (uint8_t)(a + src[i + a]); }
-			__syncthreads();
-			uint8_t* t = src; src = dst; dst = t;
+			lim -= 2 << r;                                     // indices whose partner is still inside the window
+			uint32_t lo[NQ], hi[NQ];
+#pragma unroll
+			for (int q = 0; q < NQ; q++) {
+				const uint8_t* src = S.cw[wave][q][r & 1];
+				const uint32_t a = src[lane], c = src[lane + 64];
+				lo[q] = a + src[lane + a];
+				hi[q] = lane + 64 < lim ? c + src[lane + 64 + c] : 0u;
+			}
+#pragma unroll
+			for (int q = 0; q < NQ; q++) {
+				uint8_t* dst = S.cw[wave][q][(r + 1) & 1];
+				dst[lane] = (uint8_t)lo[q];
+				if (lane + 64 < lim) dst[lane + 64] = (uint8_t)hi[q];
+			}
+			__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+			__builtin_amdgcn_wave_barrier();
 		}
-		// after 4 swaps src == S.ca holds c16; c1 must be recomputed from b where needed
+#pragma unroll
+		for (int q = 0; q < NQ; q++) c16[q] = S.cw[wave][q][0];   // four rounds: back in buffer 0, valid for indices < 98
 	}
-	// ---- node table
-	for (int q = 0; q < PPT; q++) {
-		const int p = tid + q * PT;
+	uint32_t j[NQ], n[NQ];
+#pragma unroll
+	for (int q = 0; q < NQ; q++) {
+		const int p = (wave + q * (PT / 64)) * PSEG + lane;
 		const uint32_t byte = S.b[p];
 		uint32_t delta = 1, counts = 0;
 		if (byte == COPY_FLAG) { counts = 1; }
 		else if (byte == FILL_FLAG) { counts = 1; delta = M512 ? 2u + ((S.b[p + 1] & 0x7fu) == 127u ? 1u : 0u) : 2u; }
-		else if (byte == NORMAL_FLAG) { counts = 1; delta = M512 ? 1u + S.ca[p + 1] : 17u; }
+		else if (byte == NORMAL_FLAG) { counts = 1; delta = M512 ? 1u + c16[q][lane + 1] : 17u; }
 		const uint32_t ap = cs + p;                            // absolute position
-		uint32_t j;
-		if (ap > bpos) { j = P_END; counts = 0; }              // not a node
-		else if (ap + delta > bpos) { j = P_END; counts = 0; } // block k+1 would be entered beyond bpos: not entered
-		else j = p + delta;                                    // < PC: inside, else exit offset + PC
-		S.d[p] = (uint8_t)(delta | (counts << 7));
-		J[0][p] = (uint16_t)j;
-		S.N[0][p] = (uint16_t)counts;
+		// segment-relative jump target: 0..63 inside, 64..96 = offset 0..32 into the next segment, S_END = stream ended
+		if (ap > bpos || ap + delta > bpos) { j[q] = S_END; counts = 0; }   // not a node / block k+1 would start beyond bpos
+		else j[q] = lane + delta;
+		S.dl[p] = (uint8_t)(delta | (counts << 7));
+		n[q] = counts;
+	}
+#pragma unroll
+	for (int lv = 0; lv < 6; lv++) {
+		uint32_t jj[NQ], nn[NQ];
+#pragma unroll
+		for (int q = 0; q < NQ; q++) {
+			if (KEEP) Jlv[lv][(wave + q * (PT / 64)) * PSEG + lane] = (uint8_t)j[q];
+			jj[q] = __shfl(j[q], (int)(j[q] & 63u), 64);
+			nn[q] = __shfl(n[q], (int)(j[q] & 63u), 64);
+		}
+#pragma unroll
+		for (int q = 0; q < NQ; q++)
+			if (j[q] < (uint32_t)PSEG) { j[q] = jj[q]; n[q] += nn[q]; }
+	}
+#pragma unroll
+	for (int q = 0; q < NQ; q++) {
+		const int p = (wave + q * (PT / 64)) * PSEG + lane;
+		S.sE[p] = (uint8_t)(j[q] == S_END ? S_END : j[q] - PSEG);
+		S.sN[p] = (uint8_t)n[q];
 	}
 	__syncthreads();
-	int cur = 0;
-#pragma unroll 1
-	for (int lv = 0; lv < PLV; lv++) {
-		uint16_t* Js = KEEP ? J[lv] : J[lv & 1];
-		uint16_t* Jd = KEEP ? J[lv + 1] : J[(lv + 1) & 1];
-		for (int q = 0; q < PPT; q++) {
-			const int p = tid + q * PT;
-			const uint32_t j = Js[p];
-			uint32_t n = S.N[cur][p], jj = j;
-			if (j < (uint32_t)PC) { jj = Js[j]; n += S.N[cur][j]; }
-			Jd[p] = (uint16_t)jj;
-			S.N[cur ^ 1][p] = (uint16_t)n;
-		}
-		__syncthreads();
-		cur ^= 1;
+}
+
+// walk the 16 segments of a chunk from entry offset o (0..32): returns the exit offset into the next chunk
+// (S_END if the stream ended) and the number of blocks counted; optionally records, per segment, where the chain
+// enters it and how many blocks precede it.
+__device__ __forceinline__ void parse_walk_segments(const ParseLds& S, uint32_t o, uint32_t& exit_o, uint32_t& count,
+                                                    uint8_t* seg_entry, uint16_t* seg_rank)
+{
+	uint32_t pos = o, n = 0;
+	for (int sg = 0; sg < PNSEG; sg++) {
+		if (seg_entry) { seg_entry[sg] = (uint8_t)pos; seg_rank[sg] = (uint16_t)n; }
+		if (pos == S_END) continue;
+		const uint32_t p = sg * PSEG + pos;
+		n += S.sN[p];
+		pos = S.sE[p];
 	}
-	return cur;
+	exit_o = pos;
+	count = n;
 }
 
 template <bool M512>
 __global__ __launch_bounds__(PT) void k_parse_chunks(ParseArgs A)
 {
 	__shared__ ParseLds S;
-	__shared__ uint16_t J[2][PC];
 	const int tid = threadIdx.x;
-	const uint32_t total = A.cum[A.n_frames];
-	for (uint32_t g = blockIdx.x; g < total; g += gridDim.x) {
-		const uint32_t f = find_frame(A.cum, A.n_frames, g);
-		const uint32_t cs = (g - A.cum[f]) * PC, bpos = A.bpos[f];
-		const int cur = parse_chunk_tables<M512, false>(S, J, A.bits + (size_t)f * A.stride, (uint32_t)A.stride, bpos, cs, tid);
+	// 2-D grid: y strides over frames, x over the chunks of a frame (no search for the frame of a chunk)
+	for (uint32_t f = blockIdx.y; f < A.n_frames; f += gridDim.y)
+	for (uint32_t c = blockIdx.x, g0 = A.cum[f], nch = A.cum[f + 1] - g0; c < nch; c += gridDim.x) {
+		const uint32_t g = g0 + c, cs = c * PC, bpos = A.bpos[f];
+		parse_chunk_tables<M512, false>(S, nullptr, A.bits + (size_t)f * A.stride, (uint32_t)A.stride, bpos, cs, tid);
 		if (tid < 33) {
-			const uint32_t j = J[PLV & 1][tid];
-			const uint32_t ex = (j == P_END || cs + tid > bpos) ? 0xFFu : j - PC;
-			A.summ[(size_t)g * 33 + tid] = ex << 16 | S.N[cur][tid];
+			uint32_t ex = S_END, cnt = 0;
+			if (cs + tid <= bpos) parse_walk_segments(S, (uint32_t)tid, ex, cnt, nullptr, nullptr);
+			A.summ[(size_t)g * 33 + tid] = ex << 16 | cnt;
 		}
 		__syncthreads();
 	}
@@ -816,37 +863,59 @@ template <bool M512>
 __global__ __launch_bounds__(PT) void k_parse_emit(ParseArgs A)
 {
 	__shared__ ParseLds S;
-	__shared__ uint16_t J[PLV + 1][PC];
+	__shared__ uint8_t Jlv[6][PC];
 	__shared__ uint8_t mark[PC];
-	const int tid = threadIdx.x;
-	const uint32_t total = A.cum[A.n_frames];
-	for (uint32_t g = blockIdx.x; g < total; g += gridDim.x) {
+	__shared__ uint8_t seg_entry[PNSEG];
+	__shared__ uint16_t seg_rank[PNSEG];
+	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+	for (uint32_t f = blockIdx.y; f < A.n_frames; f += gridDim.y)
+	for (uint32_t c = blockIdx.x, g0 = A.cum[f], nch = A.cum[f + 1] - g0; c < nch; c += gridDim.x) {
+		const uint32_t g = g0 + c;
 		const uint32_t ce = A.centry[g], o = ce & 0xFFu, kb = ce >> 8;
-		const uint32_t f = find_frame(A.cum, A.n_frames, g);
 		uint32_t* off = A.offsets + (size_t)f * A.nblk;
-		if (g == A.cum[f] && tid == 0) off[0] = 0;             // block 0 is entered at byte 0
+		if (c == 0 && tid == 0) off[0] = 0;                    // block 0 is entered at byte 0
 		if (o == 0xFFu) continue;                              // the chain ended before this chunk (uniform)
-		const uint32_t cs = (g - A.cum[f]) * PC, bpos = A.bpos[f];
-		const int cur = parse_chunk_tables<M512, true>(S, J, A.bits + (size_t)f * A.stride, (uint32_t)A.stride, bpos, cs, tid);
-		for (int q = 0; q < PPT; q++) mark[tid + q * PT] = 0;
+		const uint32_t cs = c * PC, bpos = A.bpos[f];
+		parse_chunk_tables<M512, true>(S, Jlv, A.bits + (size_t)f * A.stride, (uint32_t)A.stride, bpos, cs, tid);
+		if (tid == 0) { uint32_t ex, cnt; parse_walk_segments(S, o, ex, cnt, seg_entry, seg_rank); }
 		__syncthreads();
-		if (tid == 0) mark[o] = 1;
-		__syncthreads();
-#pragma unroll 1
-		for (int lv = PLV - 1; lv >= 0; lv--) {                // every node 2^lv steps behind a marked one
-			for (int q = 0; q < PPT; q++) {
-				const int p = tid + q * PT;
-				if (mark[p]) { const uint32_t j = J[lv][p]; if (j < (uint32_t)PC) mark[j] = 1; }
+		// ---- per segment (one wave): mark the nodes of the true chain top-down through the stored jump levels
+		// (every node 2^lv steps behind a marked one), then rank the counting ones and write the entry offsets
+		{
+			constexpr int NQ = PNSEG / (PT / 64);
+			uint32_t ent[NQ];
+#pragma unroll
+			for (int q = 0; q < NQ; q++) {
+				const int sg = wave + q * (PT / 64);
+				ent[q] = seg_entry[sg];
+				mark[sg * PSEG + lane] = (uint32_t)lane == ent[q] ? 1 : 0;
 			}
-			__syncthreads();
-		}
-		const uint32_t ntot = S.N[cur][o];
-		for (int q = 0; q < PPT; q++) {
-			const int p = tid + q * PT;
-			const uint32_t d = S.d[p];
-			if (mark[p] && (d & 0x80u)) {
-				const uint32_t k = kb + (ntot - S.N[cur][p]) + 1u;       // this node is block k-1; it ends where block k starts
-				if (k < A.nblk) off[k] = cs + p + (d & 0x3Fu);
+			__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+			__builtin_amdgcn_wave_barrier();
+#pragma unroll
+			for (int lv = 5; lv >= 0; lv--) {
+				uint32_t jq[NQ], mq[NQ];
+#pragma unroll
+				for (int q = 0; q < NQ; q++) {
+					const int p = (wave + q * (PT / 64)) * PSEG + lane;
+					jq[q] = Jlv[lv][p];
+					mq[q] = mark[p];
+				}
+#pragma unroll
+				for (int q = 0; q < NQ; q++)
+					if (mq[q] && jq[q] < (uint32_t)PSEG) mark[(wave + q * (PT / 64)) * PSEG + jq[q]] = 1;
+				__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+				__builtin_amdgcn_wave_barrier();
+			}
+#pragma unroll
+			for (int q = 0; q < NQ; q++) {
+				const int sg = wave + q * (PT / 64), p = sg * PSEG + lane;
+				const uint32_t d = S.dl[p];
+				if (ent[q] != S_END && mark[p] && (d & 0x80u)) {
+					const uint32_t ntot = S.sN[sg * PSEG + ent[q]];
+					const uint32_t k = kb + seg_rank[sg] + (ntot - S.sN[p]) + 1u;   // this node is block k-1; it ends where block k starts
+					if (k < A.nblk) off[k] = cs + p + (d & 0x3Fu);
+				}
 			}
 		}
 		__syncthreads();
@@ -996,13 +1065,20 @@ __global__ __launch_bounds__(DEC_T) void k_decode(DecArgs A)
 		stale = true; istale = true;
 	}
 
+	// software pipeline over the frames of the GOP: the entry offset of frame f+1 is fetched while
+	// frame f is reconstructed
+	uint32_t off_n = valid ? A.offsets[(size_t)f_lo * A.nblk + blk] : 0u;
+	uint32_t ne_n = A.nentered[f_lo], bpos_n = A.bpos[f_lo];
 	for (int f = f_lo; f < f_hi; f++) {
-		const uint32_t ne = A.nentered[f];
+		const uint32_t ne = ne_n, off_c = off_n, bpos_c = bpos_n;
+		if (f + 1 < f_hi) {
+			off_n = valid ? A.offsets[(size_t)(f + 1) * A.nblk + blk] : 0u;
+			ne_n = A.nentered[f + 1]; bpos_n = A.bpos[f + 1];
+		}
 		bool fill_written = false;
 		if (valid && blk < ne) {
 			ByteSrc src{A.bits + (size_t)f * A.stride, (uint32_t)A.stride};
-			decode_block<M512>(src, A.offsets[(size_t)f * A.nblk + blk], A.bpos[f], s_pal, cur, icol,
-			                   istale, stale, fill_written);
+			decode_block<M512>(src, off_c, bpos_c, s_pal, cur, icol, istale, stale, fill_written);
 		}
 		if (has_last) {                                        // img_data[(x-1)+(y+1)*w] of the block to the left
 			s_nb[tid] = cur[7];
@@ -1438,17 +1514,23 @@ extern "C" int agmv_hip_parse_frames_dev(agmv_hip_ctx* c, const uint8_t* d_bits,
 	A.bits = d_bits; A.stride = stride; A.bpos = d_bpos; A.offsets = d_offsets; A.nentered = d_nentered;
 	A.cum = c->d_parse_ws; A.centry = A.cum + n_frames + 1; A.summ = A.centry + maxchunks;
 	A.n_frames = n_frames; A.nblk = nblk;
-	uint32_t grid = (uint32_t)(maxchunks < (size_t)c->n_cu * 8 ? maxchunks : (size_t)c->n_cu * 8);
+	uint32_t gx = (uint32_t)(((size_t)c->n_cu * 256 + n_frames - 1) / n_frames);   // plenty of workgroups: the kernels are latency-bound
+	if (gx < 16) gx = 16;
+	if (gx > 128) gx = 128;
+	if (getenv("AGMV_PARSE_GX")) gx = (uint32_t)atoi(getenv("AGMV_PARSE_GX"));   // tuning aid
+	if (gx > cpf) gx = (uint32_t)cpf;
+	if (gx < 1) gx = 1;
+	const dim3 grid(gx, n_frames < 65535u ? n_frames : 65535u);
 	ev_mark(c, 2, s);
 	hipLaunchKernelGGL(k_parse_prefix, dim3(1), dim3(64), 0, s, A);
 	CK(hipGetLastError());
-	if (c->mode512) hipLaunchKernelGGL(k_parse_chunks<true>, dim3(grid), dim3(PT), 0, s, A);
-	else            hipLaunchKernelGGL(k_parse_chunks<false>, dim3(grid), dim3(PT), 0, s, A);
+	if (c->mode512) hipLaunchKernelGGL(k_parse_chunks<true>, grid, dim3(PT), 0, s, A);
+	else            hipLaunchKernelGGL(k_parse_chunks<false>, grid, dim3(PT), 0, s, A);
 	CK(hipGetLastError());
 	hipLaunchKernelGGL(k_parse_stitch, dim3(n_frames), dim3(64), 0, s, A);
 	CK(hipGetLastError());
-	if (c->mode512) hipLaunchKernelGGL(k_parse_emit<true>, dim3(grid), dim3(PT), 0, s, A);
-	else            hipLaunchKernelGGL(k_parse_emit<false>, dim3(grid), dim3(PT), 0, s, A);
+	if (c->mode512) hipLaunchKernelGGL(k_parse_emit<true>, grid, dim3(PT), 0, s, A);
+	else            hipLaunchKernelGGL(k_parse_emit<false>, grid, dim3(PT), 0, s, A);
 	CK(hipGetLastError());
 	ev_mark(c, 3, s);
 	return 0;

@@ -17,6 +17,7 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(HERE))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
 import oracles as O  # noqa: E402
 import synth as S  # noqa: E402
 
@@ -38,6 +39,61 @@ def encode_clip(W, H, T, mode512, first_frame_count=0):
         ents.append(e)
     enc.close()
     return frames, p0, p1, outs, ents
+
+
+REF_DRIVER = """
+import ctypes as C, sys
+L = C.CDLL(%r)
+L.CreateAGMV.restype = C.c_void_p; L.CreateAGMV.argtypes = [C.c_ulong] * 4
+sig = [C.c_void_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_ubyte] + [C.c_ulong] * 5 + [C.c_int] * 3
+L.AGMV_EncodeAGMV.argtypes = sig; L.AGMV_EncodeFullAGMV.argtypes = sig
+L.AGMV_EncodeVideo.argtypes = sig[1:]
+L.AGMV_DecodeAGMV.argtypes = [C.c_char_p, C.c_ubyte, C.c_int]
+drv, T, W, H, opt, q, comp = sys.argv[1], *[int(x) for x in sys.argv[2:]]
+if drv == "video":
+    L.AGMV_EncodeVideo(b"out.agmv", b"fr", b"f", 1, 1, T, W, H, 24, opt, q, comp)
+else:
+    a = L.CreateAGMV(T, W, H, 24)
+    (L.AGMV_EncodeAGMV if drv == "agmv" else L.AGMV_EncodeFullAGMV)(a, b"out.agmv", b"fr", b"f", 1, 1, T, W, H, 24, opt, q, comp)
+sys.exit(L.AGMV_DecodeAGMV(b"out.agmv", 1, 1))
+"""
+
+FILE_CASES = [
+    # name, driver, T, W, H, opt, quality, compression
+    ("agmv_opt3_low_lzss_64x48", "agmv", 26, 64, 48, 3, 3, 1),
+    ("agmv_opt1_mid_lzss_64x48", "agmv", 26, 64, 48, 1, 2, 1),
+    ("agmv_opt2_low_lz77_64x48", "agmv", 26, 64, 48, 2, 3, 2),
+    ("full_opt3_high_lzss_64x48", "full", 10, 64, 48, 3, 1, 1),
+    ("agmv_gba1_low_lzss_320x240", "agmv", 14, 320, 240, 5, 3, 1),
+    ("agmv_nds_low_lzss_320x240", "agmv", 14, 320, 240, 8, 3, 1),
+    ("video_opt3_low_lzss_64x48", "video", 26, 64, 48, 3, 3, 1),
+    ("c2_agmv_opt3_low_lzss_320x240", "agmv", 212, 320, 240, 3, 3, 1),
+]
+
+
+def file_goldens():
+    import subprocess
+    import tempfile
+    import hostlib as Hh
+    out = {}
+    for name, drv, T, W, H, opt, q, comp in FILE_CASES:
+        with tempfile.TemporaryDirectory() as td:
+            os.mkdir(os.path.join(td, "fr"))
+            for t in range(1, T + 1):
+                Hh.write_bmp(os.path.join(td, "fr", "f%d.bmp" % t), S.synth_frame(W, H, t))
+            r = subprocess.run([sys.executable, "-c", REF_DRIVER % O.REF_SO, drv, str(T), str(W), str(H), str(opt), str(q), str(comp)],
+                               cwd=td, stdout=subprocess.DEVNULL)
+            data = open(os.path.join(td, "out.agmv"), "rb").read()
+            nfr = int.from_bytes(data[4:8], "little")
+            h = hashlib.sha256()
+            for k in range(1, nfr + 1):
+                h.update(open(os.path.join(td, "quick_export_%d.bmp" % k), "rb").read())
+            out[name] = {"driver": drv, "T": T, "W": W, "H": H, "opt": opt, "quality": q, "compression": comp,
+                         "decode_rc": r.returncode, "file_sha": hashlib.sha256(data).hexdigest(), "file_len": len(data),
+                         "frames": nfr, "fps_field": int.from_bytes(data[18:22], "little"),
+                         "decoded_bmps_sha": h.hexdigest()}
+            print(name, out[name]["file_len"], nfr, r.returncode)
+    return out
 
 
 def main():
@@ -106,6 +162,9 @@ def main():
             lz["%s_%d" % (name, k)] = {"n_in": int(len(o)), "in_sha": sha(o), "n_out": int(n),
                                        "csize": int(cs.value), "out_sha": sha(out[:n])}
     meta["lz_320x240"] = lz
+
+    # ---- 6. whole files through the reference's sequence drivers (N2): synthetic BMP clips -> .agmv -> BMPs
+    meta["files"] = file_goldens()
 
     json.dump(meta, open(os.path.join(HERE, "golden.json"), "w"), indent=1, sort_keys=True)
     print("golden written:", sorted(os.listdir(HERE)))
