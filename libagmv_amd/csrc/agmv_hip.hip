@@ -53,6 +53,7 @@ constexpr int ENC_T = 512;          // threads per encode workgroup = 4x4 blocks
 constexpr int ENC_WAVES = ENC_T / 64;
 constexpr int MROW = 17;            // dwords per matrix row: 16 used + 1 pad (LDS bank spread)
 constexpr int DEC_T = 256;          // threads per decode workgroup
+constexpr int DEC_STAGE = DEC_T * 34 + 64;   // LDS window for a tile's bitstream bytes (33 B per block worst case + slack)
 constexpr uint32_t LUT_ENTRIES = 1u << 24;
 
 constexpr unsigned long long ST_AGG = 1ull << 32;     // look-back status tags (high word)
@@ -587,6 +588,21 @@ struct ByteSrc {
 	__device__ __forceinline__ uint32_t operator()(uint32_t pos) const { return pos < cap ? p[pos] : 0u; }
 };
 
+// bytes of one frame read through an LDS window [lo, lo+len) staged by the workgroup; anything outside falls back to
+// global memory (streams full of resync garbage can make a tile's byte range larger than the window)
+struct StagedSrc {
+	const uint8_t* lds;
+	uint32_t lo, len;
+	const uint8_t* p;
+	uint32_t cap;
+	__device__ __forceinline__ uint32_t operator()(uint32_t pos) const
+	{
+		const uint32_t d = pos - lo;
+		if (d < len) return lds[d];
+		return pos < cap ? p[pos] : 0u;
+	}
+};
+
 // K2 (serial form): one lane walks one frame's bitstream exactly like the reference's block loop
 // (src/agmv_decode.c:226-320 / 327-397) but only records where each block is entered.
 __global__ __launch_bounds__(64) void k_parse_serial(const uint8_t* __restrict__ bits, unsigned long long stride,
@@ -1027,6 +1043,8 @@ __global__ __launch_bounds__(DEC_T) void k_decode(DecArgs A)
 	__shared__ uint32_t s_pal[512];
 	__shared__ uint32_t s_nb[DEC_T];        // neighbour exchange for the last-block quirk
 	__shared__ uint32_t s_nbstale[DEC_T];
+	__shared__ __attribute__((aligned(16))) uint8_t s_bytes[DEC_STAGE];   // this tile's slice of the frame's bitstream
+	__shared__ uint32_t s_rng[2];           // [0] lowest, [1] highest entry offset of the tile's entered blocks
 	const int tid = threadIdx.x;
 	const uint32_t npx = A.w * A.h;
 	for (int i = tid; i < 512; i += DEC_T) s_pal[i] = A.pal[i];
@@ -1076,8 +1094,29 @@ __global__ __launch_bounds__(DEC_T) void k_decode(DecArgs A)
 			ne_n = A.nentered[f + 1]; bpos_n = A.bpos[f + 1];
 		}
 		bool fill_written = false;
-		if (valid && blk < ne) {
-			ByteSrc src{A.bits + (size_t)f * A.stride, (uint32_t)A.stride};
+		// ---- stage the byte range the tile's entered blocks can touch: [first entry, last entry + 33 + 8] in ONE
+		// coalesced round trip; the dependent byte reads of decode_block then hit LDS (entry offsets increase with
+		// the block index, so the range is [offset of the first lane, offset of the last entered lane])
+		const bool entered = valid && blk < ne;
+		if (tid == 0) { s_rng[0] = off_c; s_rng[1] = off_c; }
+		__syncthreads();
+		if (entered && (blk + 1 == ne || tid == DEC_T - 1 || blk + 1 == A.nblk)) s_rng[1] = off_c;   // exactly one lane: the last entered one
+		__syncthreads();
+		const uint32_t r_lo = s_rng[0] & ~3u;
+		uint32_t r_len = s_rng[1] + 48u - r_lo;
+		if (r_len > (uint32_t)DEC_STAGE) r_len = DEC_STAGE;
+		const uint8_t* fb = A.bits + (size_t)f * A.stride;
+		if (tile * DEC_T < ne) {                               // uniform: at least the first block of the tile is entered
+			for (uint32_t i = tid * 4u; i < r_len; i += DEC_T * 4u) {
+				const uint32_t pos = r_lo + i;
+				uint32_t v = 0;
+				if (pos + 4u <= (uint32_t)A.stride) v = *(const uint32_t*)(fb + pos);
+				*(uint32_t*)(s_bytes + i) = v;
+			}
+		}
+		__syncthreads();
+		if (entered) {
+			StagedSrc src{s_bytes, r_lo, r_len & ~3u, fb, (uint32_t)A.stride};
 			decode_block<M512>(src, off_c, bpos_c, s_pal, cur, icol, istale, stale, fill_written);
 		}
 		if (has_last) {                                        // img_data[(x-1)+(y+1)*w] of the block to the left
@@ -1547,6 +1586,7 @@ extern "C" int agmv_hip_decode_frames_dev(agmv_hip_ctx* c, const uint8_t* d_bits
 	if (((uintptr_t)d_out & 15u) || ((uintptr_t)d_prev & 15u) || ((uintptr_t)d_prev_iframe & 15u)) {
 		snprintf(g_err, sizeof(g_err), "agmv_hip: pixel buffers must be 16-byte aligned"); return -1;
 	}
+	if ((stride & 3u) || ((uintptr_t)d_bits & 3u)) { snprintf(g_err, sizeof(g_err), "agmv_hip: bitstream slab and stride must be 4-byte aligned"); return -1; }
 	hipStream_t s = (hipStream_t)stream;
 	DecArgs A;
 	memset(&A, 0, sizeof(A));
