@@ -591,7 +591,7 @@ struct ByteSrc {
 // bytes of one frame read through an LDS window [lo, lo+len) staged by the workgroup; anything outside falls back to
 // global memory (streams full of resync garbage can make a tile's byte range larger than the window)
 struct StagedSrc {
-	const uint8_t* lds;
+	const __attribute__((address_space(3))) uint8_t* lds;      // explicit LDS pointer: ds_read_u8, never flat_load
 	uint32_t lo, len;
 	const uint8_t* p;
 	uint32_t cap;
@@ -707,7 +707,6 @@ constexpr uint32_t S_END = 0xFFu;       // segment tables: chain left the readab
 
 struct ParseLds {
 	uint8_t b[PC + PHALO];          // staged bytes
-	uint8_t cw[PT / 64][4][2][128]; // per wave and segment slot: code-run lengths of a 128-byte window, ping/pong
 	uint8_t sE[PC];                 // per position: offset into the NEXT segment where its chain leaves this one (S_END: stream ended)
 	uint8_t sN[PC];                 // per position: blocks counted from it to the end of its segment
 	uint8_t dl[PC];                 // bits 0..5 next(p)-p, bit 7 = node counts one block
@@ -718,7 +717,7 @@ struct ParseLds {
 // >= 1 position, so 2^6 jumps leave the segment).  Because next(p)-p <= 33 < 64 a chain leaving segment s lands
 // inside segment s+1.  With KEEP the six jump levels are stored (as segment-relative bytes) for the marking pass.
 template <bool M512, bool KEEP>
-__device__ __forceinline__ void parse_chunk_tables(ParseLds& S, uint8_t (*Jlv)[PC], const uint8_t* fbits, uint32_t cap,
+__device__ __forceinline__ void parse_chunk_tables(ParseLds& S, uint32_t (&jlv)[4][6], const uint8_t* fbits, uint32_t cap,
                                                    uint32_t bpos, uint32_t cs, int tid)
 {
 	// ---- stage the chunk (+halo), dword-wide (cs is a multiple of 1024, the slab 4-byte aligned)
@@ -736,42 +735,6 @@ __device__ __forceinline__ void parse_chunk_tables(ParseLds& S, uint8_t (*Jlv)[P
 	// segments are processed side by side (q = 0..3) so their LDS / shuffle round trips overlap.
 	const int lane = tid & 63, wave = tid >> 6;
 	constexpr int NQ = PNSEG / (PT / 64);                       // 4
-	const uint8_t* c16[NQ] = {nullptr, nullptr, nullptr, nullptr};
-	if (M512) {
-		// c1 -> c2 -> c4 -> c8 -> c16 : bytes taken by 1,2,4,8,16 consecutive entry codes, over the 128-byte window
-		// that starts at the segment (a NORMAL block at the last position needs c16 of the following byte)
-#pragma unroll
-		for (int q = 0; q < NQ; q++) {
-			const uint8_t* wb = S.b + (wave + q * (PT / 64)) * PSEG;
-			S.cw[wave][q][0][lane] = (uint8_t)(1u + ((wb[lane] & 0x7fu) == 127u ? 1u : 0u));
-			S.cw[wave][q][0][lane + 64] = (uint8_t)(1u + ((wb[lane + 64] & 0x7fu) == 127u ? 1u : 0u));
-		}
-		__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-		__builtin_amdgcn_wave_barrier();
-		int lim = 128;
-#pragma unroll
-		for (int r = 0; r < 4; r++) {
-			lim -= 2 << r;                                     // indices whose partner is still inside the window
-			uint32_t lo[NQ], hi[NQ];
-#pragma unroll
-			for (int q = 0; q < NQ; q++) {
-				const uint8_t* src = S.cw[wave][q][r & 1];
-				const uint32_t a = src[lane], c = src[lane + 64];
-				lo[q] = a + src[lane + a];
-				hi[q] = lane + 64 < lim ? c + src[lane + 64 + c] : 0u;
-			}
-#pragma unroll
-			for (int q = 0; q < NQ; q++) {
-				uint8_t* dst = S.cw[wave][q][(r + 1) & 1];
-				dst[lane] = (uint8_t)lo[q];
-				if (lane + 64 < lim) dst[lane + 64] = (uint8_t)hi[q];
-			}
-			__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-			__builtin_amdgcn_wave_barrier();
-		}
-#pragma unroll
-		for (int q = 0; q < NQ; q++) c16[q] = S.cw[wave][q][0];   // four rounds: back in buffer 0, valid for indices < 98
-	}
 	uint32_t j[NQ], n[NQ];
 #pragma unroll
 	for (int q = 0; q < NQ; q++) {
@@ -780,7 +743,17 @@ __device__ __forceinline__ void parse_chunk_tables(ParseLds& S, uint8_t (*Jlv)[P
 		uint32_t delta = 1, counts = 0;
 		if (byte == COPY_FLAG) { counts = 1; }
 		else if (byte == FILL_FLAG) { counts = 1; delta = M512 ? 2u + ((S.b[p + 1] & 0x7fu) == 127u ? 1u : 0u) : 2u; }
-		else if (byte == NORMAL_FLAG) { counts = 1; delta = M512 ? 1u + c16[q][lane + 1] : 17u; }
+		else if (byte == NORMAL_FLAG) {
+			counts = 1;
+			if (M512) {
+				// 16 entry codes of 1 or 2 bytes: walked only by the lanes that sit on a NORMAL flag (rare; the whole
+				// wave skips this when none does) instead of doubling code-run lengths over every position
+				uint32_t e = p + 1;
+#pragma unroll 4
+				for (int k = 0; k < 16; k++) e += 1u + ((S.b[e] & 0x7fu) == 127u ? 1u : 0u);
+				delta = e - p;
+			} else delta = 17u;
+		}
 		const uint32_t ap = cs + p;                            // absolute position
 		// segment-relative jump target: 0..63 inside, 64..96 = offset 0..32 into the next segment, S_END = stream ended
 		if (ap > bpos || ap + delta > bpos) { j[q] = S_END; counts = 0; }   // not a node / block k+1 would start beyond bpos
@@ -790,16 +763,15 @@ __device__ __forceinline__ void parse_chunk_tables(ParseLds& S, uint8_t (*Jlv)[P
 	}
 #pragma unroll
 	for (int lv = 0; lv < 6; lv++) {
-		uint32_t jj[NQ], nn[NQ];
+		uint32_t jn[NQ];
 #pragma unroll
 		for (int q = 0; q < NQ; q++) {
-			if (KEEP) Jlv[lv][(wave + q * (PT / 64)) * PSEG + lane] = (uint8_t)j[q];
-			jj[q] = __shfl(j[q], (int)(j[q] & 63u), 64);
-			nn[q] = __shfl(n[q], (int)(j[q] & 63u), 64);
+			if (KEEP) jlv[q][lv] = j[q];
+			jn[q] = __shfl(j[q] | n[q] << 8, (int)(j[q] & 63u), 64);      // one shuffle carries (jump, count)
 		}
 #pragma unroll
 		for (int q = 0; q < NQ; q++)
-			if (j[q] < (uint32_t)PSEG) { j[q] = jj[q]; n[q] += nn[q]; }
+			if (j[q] < (uint32_t)PSEG) { j[q] = jn[q] & 0xFFu; n[q] += jn[q] >> 8; }
 	}
 #pragma unroll
 	for (int q = 0; q < NQ; q++) {
@@ -837,7 +809,8 @@ __global__ __launch_bounds__(PT) void k_parse_chunks(ParseArgs A)
 	for (uint32_t f = blockIdx.y; f < A.n_frames; f += gridDim.y)
 	for (uint32_t c = blockIdx.x, g0 = A.cum[f], nch = A.cum[f + 1] - g0; c < nch; c += gridDim.x) {
 		const uint32_t g = g0 + c, cs = c * PC, bpos = A.bpos[f];
-		parse_chunk_tables<M512, false>(S, nullptr, A.bits + (size_t)f * A.stride, (uint32_t)A.stride, bpos, cs, tid);
+		uint32_t jl_unused[4][6];
+		parse_chunk_tables<M512, false>(S, jl_unused, A.bits + (size_t)f * A.stride, (uint32_t)A.stride, bpos, cs, tid);
 		if (tid < 33) {
 			uint32_t ex = S_END, cnt = 0;
 			if (cs + tid <= bpos) parse_walk_segments(S, (uint32_t)tid, ex, cnt, nullptr, nullptr);
@@ -879,7 +852,6 @@ template <bool M512>
 __global__ __launch_bounds__(PT) void k_parse_emit(ParseArgs A)
 {
 	__shared__ ParseLds S;
-	__shared__ uint8_t Jlv[6][PC];
 	__shared__ uint8_t mark[PC];
 	__shared__ uint8_t seg_entry[PNSEG];
 	__shared__ uint16_t seg_rank[PNSEG];
@@ -892,7 +864,8 @@ __global__ __launch_bounds__(PT) void k_parse_emit(ParseArgs A)
 		if (c == 0 && tid == 0) off[0] = 0;                    // block 0 is entered at byte 0
 		if (o == 0xFFu) continue;                              // the chain ended before this chunk (uniform)
 		const uint32_t cs = c * PC, bpos = A.bpos[f];
-		parse_chunk_tables<M512, true>(S, Jlv, A.bits + (size_t)f * A.stride, (uint32_t)A.stride, bpos, cs, tid);
+		uint32_t jlv[4][6];                                    // this lane's jump levels for its four segments
+		parse_chunk_tables<M512, true>(S, jlv, A.bits + (size_t)f * A.stride, (uint32_t)A.stride, bpos, cs, tid);
 		if (tid == 0) { uint32_t ex, cnt; parse_walk_segments(S, o, ex, cnt, seg_entry, seg_rank); }
 		__syncthreads();
 		// ---- per segment (one wave): mark the nodes of the true chain top-down through the stored jump levels
@@ -914,7 +887,7 @@ __global__ __launch_bounds__(PT) void k_parse_emit(ParseArgs A)
 #pragma unroll
 				for (int q = 0; q < NQ; q++) {
 					const int p = (wave + q * (PT / 64)) * PSEG + lane;
-					jq[q] = Jlv[lv][p];
+					jq[q] = jlv[q][lv];
 					mq[q] = mark[p];
 				}
 #pragma unroll
@@ -1116,7 +1089,7 @@ __global__ __launch_bounds__(DEC_T) void k_decode(DecArgs A)
 		}
 		__syncthreads();
 		if (entered) {
-			StagedSrc src{s_bytes, r_lo, r_len & ~3u, fb, (uint32_t)A.stride};
+			StagedSrc src{(const __attribute__((address_space(3))) uint8_t*)s_bytes, r_lo, r_len & ~3u, fb, (uint32_t)A.stride};
 			decode_block<M512>(src, off_c, bpos_c, s_pal, cur, icol, istale, stale, fill_written);
 		}
 		if (has_last) {                                        // img_data[(x-1)+(y+1)*w] of the block to the left
@@ -1553,14 +1526,15 @@ extern "C" int agmv_hip_parse_frames_dev(agmv_hip_ctx* c, const uint8_t* d_bits,
 	A.bits = d_bits; A.stride = stride; A.bpos = d_bpos; A.offsets = d_offsets; A.nentered = d_nentered;
 	A.cum = c->d_parse_ws; A.centry = A.cum + n_frames + 1; A.summ = A.centry + maxchunks;
 	A.n_frames = n_frames; A.nblk = nblk;
+	const dim3 gy(1, n_frames < 65535u ? n_frames : 65535u);
+	ev_mark(c, 2, s);
 	uint32_t gx = (uint32_t)(((size_t)c->n_cu * 256 + n_frames - 1) / n_frames);   // plenty of workgroups: the kernels are latency-bound
 	if (gx < 16) gx = 16;
 	if (gx > 128) gx = 128;
 	if (getenv("AGMV_PARSE_GX")) gx = (uint32_t)atoi(getenv("AGMV_PARSE_GX"));   // tuning aid
 	if (gx > cpf) gx = (uint32_t)cpf;
 	if (gx < 1) gx = 1;
-	const dim3 grid(gx, n_frames < 65535u ? n_frames : 65535u);
-	ev_mark(c, 2, s);
+	const dim3 grid(gx, gy.y);
 	hipLaunchKernelGGL(k_parse_prefix, dim3(1), dim3(64), 0, s, A);
 	CK(hipGetLastError());
 	if (c->mode512) hipLaunchKernelGGL(k_parse_chunks<true>, grid, dim3(PT), 0, s, A);

@@ -311,13 +311,14 @@ def test_parallel_parser_matches_serial_walk(torch, hip, monkeypatch):
         monkeypatch.setenv("AGMV_HIP_PARSE", "serial")
         o_ser, n_ser = hip.parse_dev(out, sizes, n, W, H)
         torch.cuda.synchronize()
+        ne = n_ser.cpu().numpy()
         monkeypatch.delenv("AGMV_HIP_PARSE")
         o_par, n_par = hip.parse_dev(out, sizes, n, W, H)
         torch.cuda.synchronize()
         assert torch.equal(n_ser, n_par), (n_ser.cpu().numpy(), n_par.cpu().numpy())
-        ne = n_ser.cpu().numpy()
         for f in range(n):
             assert torch.equal(o_ser[f, :ne[f]], o_par[f, :ne[f]]), "mode512=%s frame %d (nentered %d of %d)" % (mode512, f, ne[f], nblk)
+        monkeypatch.delenv("AGMV_HIP_PARSE", raising=False)
 
 
 # ------------------------------------------------------------------------------- helpers
