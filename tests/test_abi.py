@@ -38,3 +38,15 @@ def test_product_never_touches_the_oracle():
             if fn.endswith((".py", ".c", ".h", ".hip", ".cpp")):
                 txt = open(os.path.join(dp, fn), errors="ignore").read()
                 assert "oracle" not in txt.lower().replace("no cpu fallback", ""), os.path.join(dp, fn)
+
+
+def test_example_program_builds_against_the_drop_in_headers(tmp_path):
+    """the reference's README flow compiles and links unchanged against include/agmv.h + libagmv.so"""
+    import subprocess
+    from libagmv_amd import build
+    build.build()
+    exe = str(tmp_path / "agmv_example")
+    subprocess.run(["gcc", os.path.join(ROOT, "examples", "encode_decode.c"), "-I" + os.path.join(ROOT, "include"),
+                    "-L" + os.path.join(ROOT, "libagmv_amd"), "-lagmv", "-lagmv_hip",
+                    "-Wl,-rpath," + os.path.join(ROOT, "libagmv_amd"), "-o", exe], check=True)
+    assert os.path.exists(exe)

@@ -83,3 +83,19 @@ def test_decode_reference_sample_file_via_c_api(golden, golden_dir, tmp_path):
         px = np.frombuffer(raw[54:], np.uint8).reshape(-1, 3).astype(np.uint32)
         pix = px[:, 2] << 16 | px[:, 1] << 8 | px[:, 0]
         assert hashlib.sha256(pix.astype(np.uint32).tobytes()).hexdigest() == g["pix_sha"][k - 1], k
+
+
+def test_c_example_runs(tmp_path):
+    """examples/encode_decode.c (the reference's README flow) end to end on the GPU"""
+    exe = str(tmp_path / "agmv_example")
+    H.lib()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.run(["gcc", os.path.join(root, "examples", "encode_decode.c"), "-I" + os.path.join(root, "include"),
+                    "-L" + os.path.join(root, "libagmv_amd"), "-lagmv", "-lagmv_hip",
+                    "-Wl,-rpath," + os.path.join(root, "libagmv_amd"), "-o", exe], check=True)
+    r = subprocess.run([exe], cwd=str(tmp_path), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    assert b"NO ERROR" in r.stdout
+    data = open(tmp_path / "example.agmv", "rb").read()
+    n = int.from_bytes(data[4:8], "little")
+    assert n == 18 and os.path.exists(tmp_path / ("quick_export_%d.bmp" % n))
