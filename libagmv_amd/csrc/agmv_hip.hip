@@ -332,28 +332,33 @@ __global__ __launch_bounds__(ENC_T, 4) void k_encode(EncArgs A)
 		int f_hi = (int)(group * 4 - A.phase) + 4;
 		if (f_hi > (int)A.n_frames) f_hi = (int)A.n_frames;
 
-		// lane-as-block geometry (classification, emission, I-frame entry plane)
+		// geometry: ONE integer division per wave (of its first block, wave-uniform); lane positions follow by adding
+		// and wrapping at the end of a block row (no per-lane divisions)
 		const uint32_t wbase = tile * ENC_T + wave * WBLK;      // first block of this wave
+		const uint32_t wb_c = wbase < A.nblk ? wbase : A.nblk - 1;
+		const uint32_t wby = __builtin_amdgcn_readfirstlane(wb_c / A.bw), wbx = wb_c - wby * A.bw;
+		auto locate = [&](uint32_t B, uint32_t& qx, uint32_t& qy) {   // block index (>= wb_c) -> block column / row
+			if (B >= A.nblk) B = A.nblk - 1;                   // blocks past the frame re-use the last valid one
+			qx = wbx + (B - wb_c); qy = wby;
+			while (qx >= A.bw) { qx -= A.bw; qy++; }
+		};
+		// lane-as-block view (classification, emission, I-frame entry plane)
 		const uint32_t blk = wbase + lane;
 		const bool valid = blk < A.nblk;
-		const uint32_t bb = valid ? blk : A.nblk - 1;
-		const uint32_t by = bb / A.bw, bx = bb - by * A.bw;
+		uint32_t bx, by;
+		locate(blk, bx, by);
 		const uint32_t poff = by * 4 * A.w + bx * 4;           // top-left pixel of the block
 
-		// quantise geometry, lane = (block, row): load i (0..3) fetches row `prow` (16 bytes) of block
-		// wbase + 16i + jb, so one instruction reads four 256-byte row segments of 16 adjacent blocks
-		// (1 KiB, full lines) and each of its four pixel columns is a 64x4-pixel patch for the LUT gather.
-		// Offsets are not kept in registers: a wave inside one block row uses immediate offsets, one
-		// crossing a row boundary adds 3*w past it, anything else (frames narrower than 64 blocks, the
-		// ragged end of the frame) recomputes the block position.
+		// quantise view, lane = (block, row): load i (0..3) fetches row `prow` (16 bytes) of block wbase + 16i + jb, so
+		// one instruction reads four 256-byte row segments of 16 adjacent blocks (1 KiB, full lines) and each of its
+		// four pixel columns is a 64x4-pixel patch for the LUT gather.  A wave inside one block row uses immediate
+		// offsets, one crossing a single row boundary adds 3*w past it, anything else (frames narrower than 64 blocks,
+		// the ragged end of the frame) locates each of its four blocks.
 		const uint32_t B0 = wbase + jb;
-		const uint32_t Bc0 = B0 < A.nblk ? B0 : A.nblk - 1;
-		const uint32_t qy0 = Bc0 / A.bw, qx0 = Bc0 - qy0 * A.bw;
+		uint32_t qx0, qy0;
+		locate(B0, qx0, qy0);
 		const uint32_t p0b = ((qy0 * 4 + prow) * A.w + qx0 * 4) * 4u, w3b = 12u * A.w;
-		const uint32_t wb_c = wbase < A.nblk ? wbase : A.nblk - 1;
-		const uint32_t row_first = wb_c / A.bw, row_last = (wbase + WBLK - 1) / A.bw;
-		const uint32_t wrapB = (row_first + 1) * A.bw;          // first block of the next block row
-		const int path = (wbase + WBLK > A.nblk || row_last > row_first + 1) ? 2 : (row_last != row_first ? 1 : 0);
+		const int path = (wbase + WBLK > A.nblk || wbx + WBLK > 2 * A.bw) ? 2 : (wbx + WBLK > A.bw ? 1 : 0);
 		auto load_frame = [&](const uint32_t* fp, uint4 (&dst)[4]) {
 			// uniform 128-bit descriptor per frame + one 32-bit byte offset per lane
 			const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)fp, 0, (int)(npx * 4u), 0x00020000);
@@ -363,29 +368,27 @@ __global__ __launch_bounds__(ENC_T, 4) void k_encode(EncArgs A)
 			} else if (path == 1) {
 #pragma unroll
 				for (int i = 0; i < 4; i++)
-					dst[i] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rs, p0b + 256 * i + (B0 + 16 * i >= wrapB ? w3b : 0u), 0, 0));
+					dst[i] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rs, p0b + 256 * i + (qx0 + 16 * i >= A.bw ? w3b : 0u), 0, 0));   // past the end of B0's own block row
 			} else {
 #pragma unroll
 				for (int i = 0; i < 4; i++) {
-					uint32_t B = B0 + 16 * i;
-					if (B >= A.nblk) B = A.nblk - 1;           // blocks past the frame re-read the last valid one
-					const uint32_t qy = B / A.bw, qx = B - qy * A.bw;
+					uint32_t qx, qy;
+					locate(B0 + 16 * i, qx, qy);
 					dst[i] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rs, ((qy * 4 + prow) * A.w + qx * 4) * 4u, 0, 0));
 				}
 			}
 		};
 
-		uint32_t irow[16];                                     // matrix row (dword index) of the I-frame entries
+		uint32_t ip[8];                                        // the GOP's I-frame entries of this block, two u16 per register
 		if (((A.first_fc + f_lo) & 3u) != 0) {                 // GOP started in an earlier batch
 #pragma unroll
 			for (int r = 0; r < 4; r++) {
-				uint2 q = *(const uint2*)(A.ientries + poff + r * A.w);
-				irow[r * 4 + 0] = (q.x & 0xffffu) * MROW; irow[r * 4 + 1] = (q.x >> 16) * MROW;
-				irow[r * 4 + 2] = (q.y & 0xffffu) * MROW; irow[r * 4 + 3] = (q.y >> 16) * MROW;
+				const uint2 q = *(const uint2*)(A.ientries + poff + r * A.w);
+				ip[2 * r] = q.x; ip[2 * r + 1] = q.y;
 			}
 		} else {
 #pragma unroll
-			for (int k = 0; k < 16; k++) irow[k] = 0;
+			for (int m = 0; m < 8; m++) ip[m] = 0;
 		}
 
 		uint4 px[4];
@@ -429,39 +432,37 @@ __global__ __launch_bounds__(ENC_T, 4) void k_encode(EncArgs A)
 				}
 				__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 				__builtin_amdgcn_wave_barrier();
-				// ---- transpose: lane = block reads its 16 entries (32 contiguous bytes)
-				uint32_t e[16];
+				// ---- transpose: lane = block reads its 16 entries (32 contiguous bytes), kept PACKED two per register
+				uint32_t ep[8];
 				{
 					const uint4 lo = *(const uint4*)(scratch + 12 + lane * 32), hi = *(const uint4*)(scratch + 12 + lane * 32 + 16);
-					e[0] = lo.x & 0xffffu; e[1] = lo.x >> 16; e[2] = lo.y & 0xffffu; e[3] = lo.y >> 16;
-					e[4] = lo.z & 0xffffu; e[5] = lo.z >> 16; e[6] = lo.w & 0xffffu; e[7] = lo.w >> 16;
-					e[8] = hi.x & 0xffffu; e[9] = hi.x >> 16; e[10] = hi.y & 0xffffu; e[11] = hi.y >> 16;
-					e[12] = hi.z & 0xffffu; e[13] = hi.z >> 16; e[14] = hi.w & 0xffffu; e[15] = hi.w >> 16;
+					ep[0] = lo.x; ep[1] = lo.y; ep[2] = lo.z; ep[3] = lo.w; ep[4] = hi.x; ep[5] = hi.y; ep[6] = hi.z; ep[7] = hi.w;
 				}
 				// ---- (C) block tests. count1 = CompareIFrameBlock vs the top-left entry colour
 				// (src/agmv_encode.c:302-352), count2 = ComparePFrameBlock vs the I-frame entries
-				// (src/agmv_encode.c:240-300); one matrix bit per pixel.
-				const uint32_t row0 = e[0] * MROW;
+				// (src/agmv_encode.c:240-300); one matrix bit per pixel (the shifter uses the low 5 bits of its amount).
+				const uint32_t e0 = ep[0] & 0xffffu, row0 = e0 * MROW;
 				uint32_t acc1 = 0, acc2 = 0, nesc = 0;
 #pragma unroll
-				for (int k = 0; k < 16; k++) {
+				for (int m = 0; m < 8; m++) {
+					const uint32_t p = ep[m], a5 = (p >> 5) & 0x7ffu, b5 = p >> 21, bh = p >> 16;
 #ifdef ABL_NOCMP
-					uint32_t w1 = e[k] * 0x9E3779B1u;
+					const uint32_t wa = p * 0x9E3779B1u, wb = bh * 0x9E3779B1u;
 #else
-					uint32_t w1 = s_mtx[row0 + (e[k] >> 5)];
+					const uint32_t wa = s_mtx[row0 + a5], wb = s_mtx[row0 + b5];
 #endif
-					acc1 = __builtin_amdgcn_alignbit(w1 >> (e[k] & 31u), acc1, 1);
-					if (M512) nesc += ((e[k] & 0xffu) >= 127u) ? 1u : 0u;
-				}
-				if (!is_i) {
-#pragma unroll
-					for (int k = 0; k < 16; k++) {
+					acc1 = __builtin_amdgcn_alignbit(wa >> (p & 31u), acc1, 1);
+					acc1 = __builtin_amdgcn_alignbit(wb >> (bh & 31u), acc1, 1);
+					if (M512) nesc += ((p & 0xffu) >= 127u ? 1u : 0u) + ((bh & 0xffu) >= 127u ? 1u : 0u);
+					if (!is_i) {
+						const uint32_t q = ip[m];
 #ifdef ABL_NOCMP
-						uint32_t w2 = (e[k] ^ irow[k]) * 0x9E3779B1u;
+						const uint32_t va = (p ^ q) * 0x9E3779B1u, vb = (bh ^ (q >> 16)) * 0x9E3779B1u;
 #else
-						uint32_t w2 = s_mtx[irow[k] + (e[k] >> 5)];
+						const uint32_t va = s_mtx[(q & 0xffffu) * MROW + a5], vb = s_mtx[(q >> 16) * MROW + b5];
 #endif
-						acc2 = __builtin_amdgcn_alignbit(w2 >> (e[k] & 31u), acc2, 1);
+						acc2 = __builtin_amdgcn_alignbit(va >> (p & 31u), acc2, 1);
+						acc2 = __builtin_amdgcn_alignbit(vb >> (bh & 31u), acc2, 1);
 					}
 				}
 				const uint32_t count1 = __popc(acc1), count2 = __popc(acc2);
@@ -469,19 +470,18 @@ __global__ __launch_bounds__(ENC_T, 4) void k_encode(EncArgs A)
 				const bool fill = !copy && count1 >= FILL_COUNT;
 				uint32_t len;
 				if (copy) len = 1;
-				else if (fill) len = M512 ? (2u + ((e[0] & 0xffu) >= 127u ? 1u : 0u)) : 2u;
+				else if (fill) len = M512 ? (2u + ((e0 & 0xffu) >= 127u ? 1u : 0u)) : 2u;
 				else len = 17u + nesc;
 				if (!valid) len = 0;
 
 				if (is_i) {                                        // iframe_entries = img_entry, :626-630
 #pragma unroll
-					for (int k = 0; k < 16; k++) irow[k] = e[k] * MROW;
+					for (int m = 0; m < 8; m++) ip[m] = ep[m];
 					if (A.ientries && (uint32_t)f == A.last_iframe && valid) {
 #pragma unroll
 						for (int r = 0; r < 4; r++) {
 							uint2 q;
-							q.x = e[r * 4 + 0] | (e[r * 4 + 1] << 16);
-							q.y = e[r * 4 + 2] | (e[r * 4 + 3] << 16);
+							q.x = ep[2 * r]; q.y = ep[2 * r + 1];
 							*(uint2*)(A.ientries + poff + r * A.w) = q;
 						}
 					}
@@ -517,24 +517,28 @@ __global__ __launch_bounds__(ENC_T, 4) void k_encode(EncArgs A)
 					} else if (fill) {
 						sp[0] = FILL_FLAG;
 						if (M512) {
-							uint32_t idx = e[0] & 0xffu, p7 = (e[0] >> 1) & 0x80u;
+							const uint32_t idx = e0 & 0xffu, p7 = (e0 >> 1) & 0x80u;
 							sp[1] = (uint8_t)(p7 | (idx < 127u ? idx : 127u));        // :382-388
 							if (idx >= 127u) sp[2] = (uint8_t)idx;
 						} else {
-							sp[1] = (uint8_t)e[0];                                     // :421
+							sp[1] = (uint8_t)e0;                                       // :421
 						}
 					} else {
 						sp[0] = NORMAL_FLAG;
 						uint32_t pos = 1;
 #pragma unroll
-						for (int k = 0; k < 16; k++) {
-							if (M512) {
-								uint32_t idx = e[k] & 0xffu, p7 = (e[k] >> 1) & 0x80u;
-								sp[pos] = (uint8_t)(p7 | (idx < 127u ? idx : 127u));    // :395-401
-								if (idx >= 127u) sp[pos + 1] = (uint8_t)idx;
-								pos += 1u + (idx >= 127u ? 1u : 0u);
-							} else {
-								sp[pos++] = (uint8_t)e[k];                             // :428-429
+						for (int m = 0; m < 8; m++) {
+#pragma unroll
+							for (int hf = 0; hf < 2; hf++) {
+								const uint32_t ek = hf ? ep[m] >> 16 : ep[m] & 0xffffu;
+								if (M512) {
+									const uint32_t idx = ek & 0xffu, p7 = (ek >> 1) & 0x80u;
+									sp[pos] = (uint8_t)(p7 | (idx < 127u ? idx : 127u));    // :395-401
+									if (idx >= 127u) sp[pos + 1] = (uint8_t)idx;
+									pos += 1u + (idx >= 127u ? 1u : 0u);
+								} else {
+									sp[pos++] = (uint8_t)ek;                               // :428-429
+								}
 							}
 						}
 					}

@@ -112,7 +112,7 @@ def test_encode_clip_hashes_golden(torch, hip, golden, name):
 
 
 @pytest.mark.parametrize("mode512", [True, False])
-@pytest.mark.parametrize("shape", [(4, 4), (8, 8), (20, 12), (2052, 4), (68, 36), (512, 64)])
+@pytest.mark.parametrize("shape", [(4, 4), (8, 8), (20, 12), (2052, 4), (68, 36), (512, 64), (280, 64), (300, 40)])
 def test_encode_vs_oracle_shapes_and_content(torch, hip, mode512, shape):
     """ragged geometries (tiles straddling block rows, a single block, one block row) and
     adversarial content (noise -> all NORMAL with escapes, flat -> all FILL/COPY)."""
