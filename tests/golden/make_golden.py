@@ -180,7 +180,29 @@ def main():
     meta["lz_320x240"] = lz
 
     # ---- 6. whole files through the reference's sequence drivers (N2): synthetic BMP clips -> .agmv -> BMPs
-    meta["files"] = file_goldens()
+    if os.environ.get("GOLDEN_SKIP_FILES") and os.path.exists(os.path.join(HERE, "golden.json")):
+        meta["files"] = json.load(open(os.path.join(HERE, "golden.json")))["files"]
+    else:
+        meta["files"] = file_goldens()
+
+    # ---- 7. the per-frame FILE* API: AGMV_EncodeHeader + AGMV_EncodeFrame x n through the reference (refshim_*_file)
+    import tempfile
+    pf = {}
+    for mode512, opt in ((1, 3), (0, 2)):
+        for comp in (1, 2):
+            W, H, T = 64, 48, 7
+            frames = [S.synth_frame(W, H, t) for t in range(T)]
+            p0, p1 = S.content_palettes(frames[:4])
+            with tempfile.TemporaryDirectory() as td:
+                path = os.path.join(td, "pf.agmv").encode()
+                a = O.ref().refshim_create(W, H, opt, comp, p0, p1)
+                O.ref().refshim_write_header(a, path)
+                for f in frames:
+                    O.ref().refshim_encode_frame_file(a, path, np.ascontiguousarray(f.reshape(-1)), 0)
+                O.ref().refshim_destroy(a)
+                data = open(path, "rb").read()
+            pf["opt%d_comp%d" % (opt, comp)] = {"W": W, "H": H, "T": T, "file_sha": hashlib.sha256(data).hexdigest(), "file_len": len(data)}
+    meta["per_frame_api"] = pf
 
     json.dump(meta, open(os.path.join(HERE, "golden.json"), "w"), indent=1, sort_keys=True)
     print("golden written:", sorted(os.listdir(HERE)))

@@ -99,3 +99,62 @@ def test_c_example_runs(tmp_path):
     data = open(tmp_path / "example.agmv", "rb").read()
     n = int.from_bytes(data[4:8], "little")
     assert n == 18 and os.path.exists(tmp_path / ("quick_export_%d.bmp" % n))
+
+
+def test_per_frame_file_api_matches_reference(golden, tmp_path):
+    """AGMV_EncodeHeader + AGMV_EncodeFrame per frame (8-byte u32 pixels, FILE* protocol) must write the file the
+    reference's own AGMV_EncodeFrame writes; then AGMV_DecodeFrameChunk per frame must give the oracle's pixels."""
+    import ctypes as C
+    import numpy as np
+    import oracles as O
+    L = H.lib()
+    libc = C.CDLL(None)
+    libc.fopen.restype = C.c_void_p
+    libc.fopen.argtypes = [C.c_char_p, C.c_char_p]
+    libc.fclose.argtypes = [C.c_void_p]
+    vp = C.c_void_p
+    L.AGMV_SetICP0.argtypes = [vp, H.u64p]
+    L.AGMV_SetICP1.argtypes = [vp, H.u64p]
+    L.AGMV_SetOPT.argtypes = [vp, C.c_int]
+    L.AGMV_SetCompression.argtypes = [vp, C.c_int]
+    L.AGMV_EncodeHeader.argtypes = [vp, vp]
+    L.AGMV_EncodeFrame.argtypes = [vp, vp, H.u64p]
+    L.AGMV_DecodeHeader.argtypes = [vp, vp]
+    L.AGMV_DecodeHeader.restype = C.c_int
+    L.AGMV_FindNextFrameChunk.argtypes = [vp]
+    L.AGMV_DecodeFrameChunk.argtypes = [vp, vp]
+    L.AGMV_DecodeFrameChunk.restype = C.c_int
+    for key, g in golden["per_frame_api"].items():
+        opt, comp = int(key[3]), int(key[-1])
+        W, Hh, T = g["W"], g["H"], g["T"]
+        frames = [S.synth_frame(W, Hh, t) for t in range(T)]
+        p0, p1 = S.content_palettes(frames[:4])
+        path = str(tmp_path / (key + ".agmv")).encode()
+        a = L.CreateAGMV(1, W, Hh, 24)
+        L.AGMV_SetOPT(a, opt)
+        L.AGMV_SetCompression(a, comp)
+        L.AGMV_SetICP0(a, p0.astype(np.uint64))
+        L.AGMV_SetICP1(a, p1.astype(np.uint64))
+        f = libc.fopen(path, b"wb")
+        L.AGMV_EncodeHeader(f, a)
+        for fr in frames:
+            L.AGMV_EncodeFrame(f, a, np.ascontiguousarray(fr.reshape(-1)).astype(np.uint64))
+        libc.fclose(f)
+        L.DestroyAGMV(a)
+        data = open(path, "rb").read()
+        assert len(data) == g["file_len"] and hashlib.sha256(data).hexdigest() == g["file_sha"], key
+        # decode frame by frame through the FILE* API; the file header says num_of_frames = 1, so drive the loop by T
+        err, info, ofr = O.oracle_decode_file(data[:4] + T.to_bytes(4, "little") + data[8:])
+        assert err == 0 and len(ofr) == T
+        d = L.CreateAGMV(1, W, Hh, 24)
+        f = libc.fopen(path, b"rb")
+        assert L.AGMV_DecodeHeader(f, d) == 0
+        for t in range(T):
+            L.AGMV_FindNextFrameChunk(f)
+            assert L.AGMV_DecodeFrameChunk(f, d) == 0
+            frame_ptr = C.c_void_p.from_address(d + 4200).value                  # agmv->frame (offset checked against the reference headers)
+            img = C.c_void_p.from_address(frame_ptr + 16).value                  # ->img_data, 8 bytes per pixel
+            pix = np.ctypeslib.as_array(C.cast(img, C.POINTER(C.c_uint64)), (W * Hh,)).astype(np.uint32)
+            assert (pix == ofr[t]["pix"]).all(), (key, t)
+        libc.fclose(f)
+        L.DestroyAGMV(d)
