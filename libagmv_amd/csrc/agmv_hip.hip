@@ -53,7 +53,8 @@ constexpr int ENC_T = 512;          // threads per encode workgroup = 4x4 blocks
 constexpr int ENC_WAVES = ENC_T / 64;
 constexpr int MROW = 17;            // dwords per matrix row: 16 used + 1 pad (LDS bank spread)
 constexpr int DEC_T = 256;          // threads per decode workgroup
-constexpr int DEC_STAGE = DEC_T * 34 + 64;   // LDS window for a tile's bitstream bytes (33 B per block worst case + slack)
+constexpr int DEC_STAGE = DEC_T * 28;   // LDS window for a tile's bitstream bytes, double-buffered (28 B per block; beyond it bytes come from global memory)
+constexpr int DEC_SR = DEC_STAGE / 4 / DEC_T;   // dwords of the window each lane carries from global memory to LDS
 constexpr uint32_t LUT_ENTRIES = 1u << 24;
 
 constexpr unsigned long long ST_AGG = 1ull << 32;     // look-back status tags (high word)
@@ -650,30 +651,36 @@ __global__ __launch_bounds__(64) void k_parse_serial(const uint8_t* __restrict__
 
 // ----------------------------------------------------------------------------------------------
 // K2 (parallel form).  The block loop of the reference (src/agmv_decode.c:226-320) is a chain:
-// block k+1 is entered where block k ended.  Every byte position p <= bpos is a chain node:
-//   not a flag  -> next = p+1, counts 0 blocks                      (the resync of :236-243)
-//   COPY        -> next = p+1
-//   FILL        -> next = p+1+c(p+1)        c(q) = 1, or 2 if (byte[q]&0x7f)==127 (512 colours)
-//   NORMAL      -> next = 16 codes after p+1 (found by 4 rounds of pointer doubling over c)
-// and block k+1's entry offset is next(flag node of block k).  next(p)-p <= 33, so a chunk of
-// 1024 positions is summarised by a map {entry offset 0..32} -> (exit offset, blocks counted),
-// built with 10 rounds of pointer doubling in LDS (k_parse_chunks).  One wave per frame then
-// threads the chunks together with shuffles (k_parse_stitch), and k_parse_emit marks the true
-// chain top-down through the stored doubling levels and writes the entry offsets.
+// block k+1 is entered where block k ended, and an entry position that does not hold a flag byte
+// slides forward to the next flag-valued byte (the resync of :236-243).  So the only positions
+// that can start a block are the flag-valued bytes: the NODES.  A node at p ends at
+//   COPY   -> p+1        FILL -> p+2 (+1 after an escape code, 512 colours)
+//   NORMAL -> 16 codes of 1 or 2 bytes after p+1
+// and its successor is the first node at or after that end.  next(p)-p <= 33, so a chunk of PC
+// bytes is summarised by a map {entry offset 0..32} -> (exit offset, blocks counted).
+// k_parse_chunks (one WAVE per chunk, no workgroup barriers): flags are found with ballots, ranked
+// with popcounts into a dense node list, each node's end is computed by one lane, and the chain
+// is resolved by pointer doubling over the node list -- the work is proportional to the number
+// of blocks in the chunk, not to its bytes.  One wave per frame then threads the chunk maps
+// together (k_parse_stitch), and k_parse_emit rebuilds the node list, marks the nodes of the
+// true chain (three doubling levels + a walk in steps of 8 nodes) and writes the entry offsets,
+// a node's block number being the popcount of marked nodes before it.
 // ----------------------------------------------------------------------------------------------
-constexpr int PC = 1024;        // positions per chunk
-constexpr int PT = 256;         // threads per chunk workgroup
-constexpr int PPT = PC / PT;    // positions per thread
-constexpr int PLV = 10;         // doubling levels: 2^10 nodes >= nodes in a chunk
+constexpr int PC = 512;         // bytes per chunk (one wave)
+constexpr int PNSEG = PC / 64;  // ballot segments per chunk
+constexpr int PLV = 9;          // doubling levels: 2^9 >= nodes in a chunk
+constexpr int PEL = 3;          // k_parse_emit: levels kept for marking; the chain is walked 2^PEL nodes at a time
 constexpr int PHALO = 64;       // bytes staged beyond the chunk (a block spans <= 33)
-constexpr uint32_t P_END = 0xFFFFu;   // chain left the readable stream (position > bpos)
+constexpr uint32_t J_EXIT = 0x8000u;    // jump leaves the chunk: J_EXIT | offset into the next chunk
+constexpr uint32_t J_END = 0xFFFFu;     // chain left the readable stream (position > bpos)
+constexpr uint32_t X_END = 63u;         // chunk map: exit code of an ended chain
 
 struct ParseArgs {
 	const uint8_t* bits;
 	unsigned long long stride;
 	const uint32_t* bpos;
 	uint32_t* cum;          // [n_frames+1] exclusive prefix of chunks per frame
-	uint32_t* summ;         // [chunk][33] exit<<16 | count   (exit 0xff: chain ended in the chunk)
+	uint16_t* summ;         // [chunk][33] exit<<10 | count   (exit X_END: chain ended in the chunk)
 	uint32_t* centry;       // [chunk] kbase<<8 | entry offset (0xff: chain never reaches the chunk)
 	uint32_t* offsets;
 	uint32_t* nentered;
@@ -694,224 +701,213 @@ __global__ __launch_bounds__(64) void k_parse_prefix(ParseArgs A)
 	if (lane == 0) A.cum[A.n_frames] = run;
 }
 
-__device__ __forceinline__ uint32_t find_frame(const uint32_t* cum, uint32_t n, uint32_t g)
+__device__ __forceinline__ void wave_lds_sync()
 {
-	uint32_t lo = 0, hi = n;                                   // largest f with cum[f] <= g
-	while (hi - lo > 1) {
-		const uint32_t mid = (lo + hi) >> 1;
-		if (cum[mid] <= g) lo = mid; else hi = mid;
-	}
-	return lo;
+	__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+	__builtin_amdgcn_wave_barrier();
 }
 
-// LDS layout shared by k_parse_chunks / k_parse_emit
-constexpr int PSEG = 64;                // positions per segment = one wave, chain doubling by shuffles
-constexpr int PNSEG = PC / PSEG;        // 16 segments per chunk
-constexpr uint32_t S_END = 0xFFu;       // segment tables: chain left the readable stream
-
+// LDS of one wave's chunk.  NLV jump tables: 2 (ping-pong, k_parse_chunks) or PEL+1 (kept levels, k_parse_emit).
+template <int NLV>
 struct ParseLds {
-	uint8_t b[PC + PHALO];          // staged bytes
-	uint8_t sE[PC];                 // per position: offset into the NEXT segment where its chain leaves this one (S_END: stream ended)
-	uint8_t sN[PC];                 // per position: blocks counted from it to the end of its segment
-	uint8_t dl[PC];                 // bits 0..5 next(p)-p, bit 7 = node counts one block
+	uint8_t b[PC + PHALO];                  // staged bytes
+	uint16_t rank_at[PC];                   // position -> nodes before it = index of the first node at or after it
+	uint16_t npos[PC];                      // node -> position in the chunk
+	uint16_t jl[NLV][PC];                   // node -> jump target (node index | J_EXIT+offset | J_END)
 };
 
-// Per chunk: node table (LDS, 4 barrier rounds for the 16-code run lengths), then per 64-position segment the
-// chain is resolved by pointer doubling IN REGISTERS: lane = position, 6 rounds of two shuffles (a node advances
-// >= 1 position, so 2^6 jumps leave the segment).  Because next(p)-p <= 33 < 64 a chain leaving segment s lands
-// inside segment s+1.  With KEEP the six jump levels are stored (as segment-relative bytes) for the marking pass.
-template <bool M512, bool KEEP>
-__device__ __forceinline__ void parse_chunk_tables(ParseLds& S, uint32_t (&jlv)[4][6], const uint8_t* fbits, uint32_t cap,
-                                                   uint32_t bpos, uint32_t cs, int tid)
+// Build the node list of chunk [cs, cs+PC): rank_at, npos, and per node the end of its block (eo, bit 15 = the
+// block counts, i.e. the next one starts inside the stream) and its successor (jl[0]).  Returns the node count.
+template <bool M512, int NLV>
+__device__ __forceinline__ uint32_t parse_chunk_nodes(ParseLds<NLV>& S, uint16_t* eo, uint16_t* n0, uint8_t* mark,
+                                                      const uint8_t* fbits, uint32_t cap, uint32_t bpos, uint32_t cs, int lane)
 {
-	// ---- stage the chunk (+halo), dword-wide (cs is a multiple of 1024, the slab 4-byte aligned)
-	for (int i = tid; i < (PC + PHALO) / 4; i += PT) {
+	// ---- stage the chunk (+halo), dword-wide (cs and the slab stride are multiples of 4)
+#pragma unroll
+	for (int i = lane; i < (PC + PHALO) / 4; i += 64) {
 		const uint32_t pos = cs + 4u * i;
-		uint32_t v = 0;
-		if (pos + 4u <= cap) v = *(const uint32_t*)(fbits + pos);
-		else
-			for (uint32_t q = 0; q < 4; q++)
-				if (pos + q < cap) v |= (uint32_t)fbits[pos + q] << (8 * q);
-		((uint32_t*)S.b)[i] = v;
+		((uint32_t*)S.b)[i] = pos < cap ? *(const uint32_t*)(fbits + pos) : 0u;
 	}
-	__syncthreads();
-	// ---- segments: wave w takes segments w, w+4, w+8, w+12.  Everything below is wave-local and the four
-	// segments are processed side by side (q = 0..3) so their LDS / shuffle round trips overlap.
-	const int lane = tid & 63, wave = tid >> 6;
-	constexpr int NQ = PNSEG / (PT / 64);                       // 4
-	uint32_t j[NQ], n[NQ];
+	wave_lds_sync();
+	// ---- nodes = flag-valued bytes at positions <= bpos, ranked by ballot + popcount
+	uint32_t mtot = 0, by[PNSEG];
 #pragma unroll
-	for (int q = 0; q < NQ; q++) {
-		const int p = (wave + q * (PT / 64)) * PSEG + lane;
-		const uint32_t byte = S.b[p];
-		uint32_t delta = 1, counts = 0;
-		if (byte == COPY_FLAG) { counts = 1; }
-		else if (byte == FILL_FLAG) { counts = 1; delta = M512 ? 2u + ((S.b[p + 1] & 0x7fu) == 127u ? 1u : 0u) : 2u; }
-		else if (byte == NORMAL_FLAG) {
-			counts = 1;
-			if (M512) {
-				// 16 entry codes of 1 or 2 bytes: walked only by the lanes that sit on a NORMAL flag (rare; the whole
-				// wave skips this when none does) instead of doubling code-run lengths over every position
-				uint32_t e = p + 1;
-#pragma unroll 4
-				for (int k = 0; k < 16; k++) e += 1u + ((S.b[e] & 0x7fu) == 127u ? 1u : 0u);
-				delta = e - p;
-			} else delta = 17u;
-		}
-		const uint32_t ap = cs + p;                            // absolute position
-		// segment-relative jump target: 0..63 inside, 64..96 = offset 0..32 into the next segment, S_END = stream ended
-		if (ap > bpos || ap + delta > bpos) { j[q] = S_END; counts = 0; }   // not a node / block k+1 would start beyond bpos
-		else j[q] = lane + delta;
-		S.dl[p] = (uint8_t)(delta | (counts << 7));
-		n[q] = counts;
-	}
+	for (int sg = 0; sg < PNSEG; sg++) by[sg] = S.b[sg * 64 + lane];
 #pragma unroll
-	for (int lv = 0; lv < 6; lv++) {
-		uint32_t jn[NQ];
-#pragma unroll
-		for (int q = 0; q < NQ; q++) {
-			if (KEEP) jlv[q][lv] = j[q];
-			jn[q] = __shfl(j[q] | n[q] << 8, (int)(j[q] & 63u), 64);      // one shuffle carries (jump, count)
-		}
-#pragma unroll
-		for (int q = 0; q < NQ; q++)
-			if (j[q] < (uint32_t)PSEG) { j[q] = jn[q] & 0xFFu; n[q] += jn[q] >> 8; }
-	}
-#pragma unroll
-	for (int q = 0; q < NQ; q++) {
-		const int p = (wave + q * (PT / 64)) * PSEG + lane;
-		S.sE[p] = (uint8_t)(j[q] == S_END ? S_END : j[q] - PSEG);
-		S.sN[p] = (uint8_t)n[q];
-	}
-	__syncthreads();
-}
-
-// walk the 16 segments of a chunk from entry offset o (0..32): returns the exit offset into the next chunk
-// (S_END if the stream ended) and the number of blocks counted; optionally records, per segment, where the chain
-// enters it and how many blocks precede it.
-__device__ __forceinline__ void parse_walk_segments(const ParseLds& S, uint32_t o, uint32_t& exit_o, uint32_t& count,
-                                                    uint8_t* seg_entry, uint16_t* seg_rank)
-{
-	uint32_t pos = o, n = 0;
 	for (int sg = 0; sg < PNSEG; sg++) {
-		if (seg_entry) { seg_entry[sg] = (uint8_t)pos; seg_rank[sg] = (uint16_t)n; }
-		if (pos == S_END) continue;
-		const uint32_t p = sg * PSEG + pos;
-		n += S.sN[p];
-		pos = S.sE[p];
+		const uint32_t p = sg * 64 + lane;
+		const bool node = is_flag(by[sg]) && cs + p <= bpos;
+		const unsigned long long m = __ballot(node);
+		const uint32_t r = mtot + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+		S.rank_at[p] = (uint16_t)r;
+		if (node) S.npos[r] = (uint16_t)p;
+		mtot += (uint32_t)__popcll(m);
 	}
-	exit_o = pos;
-	count = n;
+	wave_lds_sync();
+	// ---- one lane per node: where its block ends, and the node that follows
+	const bool more = cs + PC <= bpos;                         // the stream continues into the next chunk
+	for (uint32_t k = lane; k < mtot; k += 64) {
+		const uint32_t p = S.npos[k], byte = S.b[p];
+		uint32_t e = p + 1u;
+		if (byte == FILL_FLAG) e += M512 ? 1u + ((S.b[p + 1] & 0x7fu) == 127u ? 1u : 0u) : 1u;
+		else if (byte == NORMAL_FLAG) {
+			if (M512) {
+#pragma unroll 4
+				for (int i = 0; i < 16; i++) e += 1u + ((S.b[e] & 0x7fu) == 127u ? 1u : 0u);
+			} else e += 16u;
+		}
+		uint32_t j = J_END, n = 0;
+		if (cs + e <= bpos) {                                  // block k+1 starts inside the stream: this one counts
+			n = 1;
+			if (e >= (uint32_t)PC) j = J_EXIT | (e - PC);
+			else {
+				const uint32_t nx = S.rank_at[e];                  // a non-flag entry slides to the next node (:236-243)
+				j = nx < mtot ? nx : (more ? J_EXIT : J_END);
+			}
+		}
+		S.jl[0][k] = (uint16_t)j;
+		if (eo) eo[k] = (uint16_t)(e | n << 15);
+		if (n0) n0[k] = (uint16_t)n;
+		if (mark) mark[k] = 0;
+	}
+	wave_lds_sync();
+	return mtot;
 }
 
 template <bool M512>
-__global__ __launch_bounds__(PT) void k_parse_chunks(ParseArgs A)
+__global__ __launch_bounds__(64) void k_parse_chunks(ParseArgs A)
 {
-	__shared__ ParseLds S;
-	const int tid = threadIdx.x;
+	__shared__ ParseLds<2> S;
+	__shared__ uint16_t nn[2][PC];                             // node -> blocks counted along its jump (ping-pong)
+	const int lane = threadIdx.x;
 	// 2-D grid: y strides over frames, x over the chunks of a frame (no search for the frame of a chunk)
 	for (uint32_t f = blockIdx.y; f < A.n_frames; f += gridDim.y)
 	for (uint32_t c = blockIdx.x, g0 = A.cum[f], nch = A.cum[f + 1] - g0; c < nch; c += gridDim.x) {
 		const uint32_t g = g0 + c, cs = c * PC, bpos = A.bpos[f];
-		uint32_t jl_unused[4][6];
-		parse_chunk_tables<M512, false>(S, jl_unused, A.bits + (size_t)f * A.stride, (uint32_t)A.stride, bpos, cs, tid);
-		if (tid < 33) {
-			uint32_t ex = S_END, cnt = 0;
-			if (cs + tid <= bpos) parse_walk_segments(S, (uint32_t)tid, ex, cnt, nullptr, nullptr);
-			A.summ[(size_t)g * 33 + tid] = ex << 16 | cnt;
+		const uint32_t mtot = parse_chunk_nodes<M512>(S, nullptr, nn[0], nullptr, A.bits + (size_t)f * A.stride, (uint32_t)A.stride, bpos, cs, lane);
+		// ---- pointer doubling over the node list until every chain has left the chunk
+		uint32_t lv = 0;
+		for (; lv < (uint32_t)PLV; lv++) {
+			const uint16_t *js = S.jl[lv & 1u], *ns = nn[lv & 1u];
+			uint16_t *jd = S.jl[(lv + 1u) & 1u], *nd = nn[(lv + 1u) & 1u];
+			bool active = false;
+			for (uint32_t k = lane; k < mtot; k += 64) {
+				uint32_t j = js[k], n = ns[k];
+				if (j < J_EXIT) { n += ns[j]; j = js[j]; active |= j < J_EXIT; }
+				jd[k] = (uint16_t)j;
+				nd[k] = (uint16_t)n;
+			}
+			wave_lds_sync();
+			if (!__ballot(active)) { lv++; break; }
 		}
-		__syncthreads();
+		if (lane < 33) {
+			uint32_t ex = X_END, cnt = 0;
+			if (cs + lane <= bpos) {
+				const uint32_t k0 = S.rank_at[lane];
+				if (k0 >= mtot) { if (cs + PC <= bpos) ex = 0; }
+				else {
+					const uint32_t j = S.jl[lv & 1u][k0];
+					cnt = nn[lv & 1u][k0];
+					if (j != J_END) ex = j & 0x3Fu;
+				}
+			}
+			A.summ[(size_t)g * 33 + lane] = (uint16_t)(ex << 10 | cnt);
+		}
+		wave_lds_sync();
 	}
 }
 
-// one wave per frame: thread the chunk maps together.  Rows are fetched 8 chunks ahead (lane j holds
-// map[j]); the dependent step is a shuffle, not a memory access.
+// one wave per frame: thread the chunk maps together.  Rows are fetched a batch of 32 chunks ahead (lane j holds
+// map[j]; unconditional clamped loads so that a whole batch is in flight while the previous one is consumed); the
+// chain state (entry offset, blocks so far) is wave-uniform, so the dependent step is a v_readlane and scalar
+// arithmetic, not a memory access.
+constexpr int PSB = 32;
 __global__ __launch_bounds__(64) void k_parse_stitch(ParseArgs A)
 {
 	const uint32_t f = blockIdx.x;
 	const int lane = threadIdx.x;
-	const uint32_t c0 = A.cum[f], nch = A.cum[f + 1] - c0;
+	const uint32_t c0 = A.cum[f], nch = A.cum[f + 1] - c0;     // nch >= 1
+	const uint16_t* rows = A.summ + (size_t)c0 * 33 + (lane < 33 ? lane : 0);
 	uint32_t o = 0, kb = 0;
-	for (uint32_t c = 0; c < nch; c += 8) {
-		uint32_t row[8];
+	uint32_t nxt[PSB];
 #pragma unroll
-		for (int u = 0; u < 8; u++)
-			row[u] = (c + u < nch && lane < 33) ? A.summ[(size_t)(c0 + c + u) * 33 + lane] : 0u;
+	for (int u = 0; u < PSB; u++) nxt[u] = rows[(size_t)min((uint32_t)u, nch - 1u) * 33];
+	for (uint32_t c = 0; c < nch; c += PSB) {
+		uint32_t row[PSB];
 #pragma unroll
-		for (int u = 0; u < 8; u++) {
-			if (c + u < nch) {
-				if (lane == 0) A.centry[c0 + c + u] = kb << 8 | o;
-				if (o != 0xFFu) {
-					const uint32_t v = __shfl(row[u], (int)o, 64);
-					kb += v & 0xFFFFu;
-					o = v >> 16;
-				}
+		for (int u = 0; u < PSB; u++) row[u] = nxt[u];
+#pragma unroll
+		for (int u = 0; u < PSB; u++) nxt[u] = rows[(size_t)min(c + PSB + u, nch - 1u) * 33];
+		uint32_t mine = 0;                                     // lane u: centry of chunk c+u
+#pragma unroll
+		for (int u = 0; u < PSB; u++) {
+			if (lane == u) mine = kb << 8 | o;
+			if (c + u < nch && o != 0xFFu) {
+				const uint32_t v = __builtin_amdgcn_readlane(row[u], __builtin_amdgcn_readfirstlane(o));
+				kb += v & 0x3FFu;
+				o = (v >> 10) == X_END ? 0xFFu : v >> 10;
 			}
 		}
+		if (lane < PSB && c + lane < nch) A.centry[c0 + c + lane] = mine;
 	}
 	if (lane == 0) A.nentered[f] = min(A.nblk, kb + 1u);
 }
 
 template <bool M512>
-__global__ __launch_bounds__(PT) void k_parse_emit(ParseArgs A)
+__global__ __launch_bounds__(64) void k_parse_emit(ParseArgs A)
 {
-	__shared__ ParseLds S;
+	__shared__ ParseLds<PEL + 1> S;
+	__shared__ uint16_t eo[PC];                                // node -> end of its block (chunk-relative, <= PC+32) | counts << 15
 	__shared__ uint8_t mark[PC];
-	__shared__ uint8_t seg_entry[PNSEG];
-	__shared__ uint16_t seg_rank[PNSEG];
-	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+	const int lane = threadIdx.x;
 	for (uint32_t f = blockIdx.y; f < A.n_frames; f += gridDim.y)
 	for (uint32_t c = blockIdx.x, g0 = A.cum[f], nch = A.cum[f + 1] - g0; c < nch; c += gridDim.x) {
 		const uint32_t g = g0 + c;
 		const uint32_t ce = A.centry[g], o = ce & 0xFFu, kb = ce >> 8;
 		uint32_t* off = A.offsets + (size_t)f * A.nblk;
-		if (c == 0 && tid == 0) off[0] = 0;                    // block 0 is entered at byte 0
+		if (c == 0 && lane == 0) off[0] = 0;                   // block 0 is entered at byte 0
 		if (o == 0xFFu) continue;                              // the chain ended before this chunk (uniform)
+		if (kb + 1u >= A.nblk) continue;                       // every block this chunk could enter is beyond the frame
 		const uint32_t cs = c * PC, bpos = A.bpos[f];
-		uint32_t jlv[4][6];                                    // this lane's jump levels for its four segments
-		parse_chunk_tables<M512, true>(S, jlv, A.bits + (size_t)f * A.stride, (uint32_t)A.stride, bpos, cs, tid);
-		if (tid == 0) { uint32_t ex, cnt; parse_walk_segments(S, o, ex, cnt, seg_entry, seg_rank); }
-		__syncthreads();
-		// ---- per segment (one wave): mark the nodes of the true chain top-down through the stored jump levels
-		// (every node 2^lv steps behind a marked one), then rank the counting ones and write the entry offsets
-		{
-			constexpr int NQ = PNSEG / (PT / 64);
-			uint32_t ent[NQ];
+		const uint32_t mtot = parse_chunk_nodes<M512>(S, eo, nullptr, mark, A.bits + (size_t)f * A.stride, (uint32_t)A.stride, bpos, cs, lane);
+		const uint32_t k0 = cs + o <= bpos ? S.rank_at[o] : mtot;
+		if (k0 < mtot) {
+			// PEL rounds of pointer doubling, then one lane walks the true chain 2^PEL nodes at a time and the kept
+			// levels fill in the nodes between (every node 2^lv steps behind a marked one)
 #pragma unroll
-			for (int q = 0; q < NQ; q++) {
-				const int sg = wave + q * (PT / 64);
-				ent[q] = seg_entry[sg];
-				mark[sg * PSEG + lane] = (uint32_t)lane == ent[q] ? 1 : 0;
-			}
-			__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-			__builtin_amdgcn_wave_barrier();
-#pragma unroll
-			for (int lv = 5; lv >= 0; lv--) {
-				uint32_t jq[NQ], mq[NQ];
-#pragma unroll
-				for (int q = 0; q < NQ; q++) {
-					const int p = (wave + q * (PT / 64)) * PSEG + lane;
-					jq[q] = jlv[q][lv];
-					mq[q] = mark[p];
+			for (int lv = 0; lv < PEL; lv++) {
+				for (uint32_t k = lane; k < mtot; k += 64) {
+					uint32_t j = S.jl[lv][k];
+					if (j < J_EXIT) j = S.jl[lv][j];
+					S.jl[lv + 1][k] = (uint16_t)j;
 				}
-#pragma unroll
-				for (int q = 0; q < NQ; q++)
-					if (mq[q] && jq[q] < (uint32_t)PSEG) mark[(wave + q * (PT / 64)) * PSEG + jq[q]] = 1;
-				__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-				__builtin_amdgcn_wave_barrier();
+				wave_lds_sync();
 			}
+			if (lane == 0)
+				for (uint32_t k = k0; k < J_EXIT; k = S.jl[PEL][k]) mark[k] = 1;
+			wave_lds_sync();
 #pragma unroll
-			for (int q = 0; q < NQ; q++) {
-				const int sg = wave + q * (PT / 64), p = sg * PSEG + lane;
-				const uint32_t d = S.dl[p];
-				if (ent[q] != S_END && mark[p] && (d & 0x80u)) {
-					const uint32_t ntot = S.sN[sg * PSEG + ent[q]];
-					const uint32_t k = kb + seg_rank[sg] + (ntot - S.sN[p]) + 1u;   // this node is block k-1; it ends where block k starts
-					if (k < A.nblk) off[k] = cs + p + (d & 0x3Fu);
+			for (int lv = PEL - 1; lv >= 0; lv--) {
+				for (uint32_t k = lane; k < mtot; k += 64) {
+					const uint32_t j = S.jl[lv][k];
+					if (mark[k] && j < J_EXIT) mark[j] = 1;
 				}
+				wave_lds_sync();
+			}
+			// nodes are in stream order, so a counting node's rank on the chain is the number of marked counting
+			// nodes before it; it is block kb+rank and ends where block kb+rank+1 is entered
+			uint32_t base = kb + 1u;
+			for (uint32_t kg = 0; kg < mtot; kg += 64) {
+				const uint32_t k = kg + lane;
+				const uint32_t ev = k < mtot ? eo[k] : 0u;
+				const bool on = k < mtot && mark[k] && (ev & 0x8000u);
+				const unsigned long long m = __ballot(on);
+				const uint32_t kk = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+				if (on && kk < A.nblk) off[kk] = cs + (ev & 0x7FFFu);
+				base += (uint32_t)__popcll(m);
 			}
 		}
-		__syncthreads();
+		wave_lds_sync();
 	}
 }
 
@@ -991,6 +987,83 @@ __device__ __forceinline__ void decode_block(const Src& src, uint32_t bitpos, co
 	}
 }
 
+// decode_block for a block whose bytes sit in the workgroup's LDS window, with the dependent byte -> byte -> palette
+// round trips of the reference walk taken apart: ONE round of reads fetches the flag, the two bytes behind it and the
+// 36 bytes a NORMAL body can span; which of those are escape codes ((b & 0x7f) == 127) becomes a bit mask, the 16
+// code positions are walked in registers, and the 32 code bytes and then the 16 palette entries are fetched as
+// independent reads.  Anything unusual (no flag at the entry offset, a block that over-runs bpos, bytes outside the
+// window) takes the generic walk above, which is the reference's loop verbatim.
+template <bool M512>
+__device__ __forceinline__ void decode_block_staged(const StagedSrc& src, uint32_t off, const uint32_t bpos,
+                                                    const uint32_t* pal, uint32_t (&cur)[16], const uint32_t (&icol)[16],
+                                                    bool istale, bool& stale, bool& fill_written)
+{
+	typedef const __attribute__((address_space(3))) uint8_t* lds8;
+	typedef const __attribute__((address_space(3))) uint32_t* lds32;
+	const uint32_t d = off - src.lo;
+	bool slow = true;
+	fill_written = false;
+	if (off >= src.lo && d + 44u <= src.len) {                 // flag + 33 bytes + alignment slack inside the window
+		const lds8 p = src.lds + d;
+		const uint32_t b0 = p[0], b1 = p[1], b2 = p[2];
+		uint32_t m = 0;                                        // bit t: the byte at off+1+t is an escape code
+		if (M512) {
+			const uint32_t d1 = d + 1u, a = d1 & ~3u;
+			unsigned long long em = 0;
+#pragma unroll
+			for (int k = 0; k < 9; k++) {
+				const uint32_t w = *(lds32)(src.lds + a + 4u * k);
+				const uint32_t z = ((w & 0x7f7f7f7fu) + 0x01010101u) & 0x80808080u;     // bit 7 of every byte equal to 127
+				const uint32_t nib = ((z >> 7) | (z >> 14) | (z >> 21) | (z >> 28)) & 0xFu;
+				em |= (unsigned long long)nib << (4 * k);
+			}
+			m = (uint32_t)(em >> (d1 & 3u));
+		}
+		if (b0 == COPY_FLAG) {                                 // no over-run check, :281-290
+#pragma unroll
+			for (int k = 0; k < 16; k++) cur[k] = icol[k];
+			stale = istale;
+			slow = false;
+		} else if (b0 == FILL_FLAG) {
+			uint32_t ci = b1, end = off + 2u;
+			if (M512) {
+				const bool esc = (b1 & 0x7fu) == 127u;
+				ci = ((b1 & 0x80u) << 1) + (esc ? b2 : (b1 & 0x7fu));
+				end += esc ? 1u : 0u;
+			}
+			const uint32_t color = pal[ci];
+			if (!(end > bpos)) {
+#pragma unroll
+				for (int k = 0; k < 16; k++) cur[k] = color;
+				stale = false;
+				fill_written = true;
+			}
+			slow = false;
+		} else if (b0 == NORMAL_FLAG) {
+			uint32_t ci[16], pos = 0;
+#pragma unroll
+			for (int i = 0; i < 16; i++) {
+				const uint32_t f0 = p[1u + pos], f1 = p[2u + pos];
+				if (M512) {
+					const uint32_t esc = (m >> pos) & 1u;
+					ci[i] = ((f0 & 0x80u) << 1) + (esc ? f1 : (f0 & 0x7fu));
+					pos += 1u + esc;
+				} else {
+					ci[i] = f0;
+					pos += 1u;
+				}
+			}
+			if (off + 1u + pos <= bpos) {                      // every code ends inside the stream: all 16 pixels are stored
+#pragma unroll
+				for (int k = 0; k < 16; k++) cur[k] = pal[ci[k]];
+				stale = false;
+				slow = false;
+			}
+		}
+	}
+	if (slow) decode_block<M512>(src, off, bpos, pal, cur, icol, istale, stale, fill_written);
+}
+
 __device__ __forceinline__ void load_block(const uint32_t* frame, uint32_t poff, uint32_t w, uint32_t (&v)[16])
 {
 #pragma unroll
@@ -1015,17 +1088,19 @@ __device__ __forceinline__ void store_block(uint32_t* frame, uint32_t poff, uint
 // outside the GOP (not rewritten since the GOP started) is flagged in `dirty` and repaired by
 // k_fixup; everything else is final.
 template <bool M512>
-__global__ __launch_bounds__(DEC_T) void k_decode(DecArgs A)
+#ifndef DEC_WPE
+#define DEC_WPE 4
+#endif
+__global__ __launch_bounds__(DEC_T, DEC_WPE) void k_decode(DecArgs A)
 {
 	__shared__ uint32_t s_pal[512];
 	__shared__ uint32_t s_nb[DEC_T];        // neighbour exchange for the last-block quirk
 	__shared__ uint32_t s_nbstale[DEC_T];
-	__shared__ __attribute__((aligned(16))) uint8_t s_bytes[DEC_STAGE];   // this tile's slice of the frame's bitstream
-	__shared__ uint32_t s_rng[2];           // [0] lowest, [1] highest entry offset of the tile's entered blocks
+	__shared__ __attribute__((aligned(16))) uint8_t s_bytes[2][DEC_STAGE];   // this tile's slice of the frame's bitstream (frame parity)
+	__shared__ uint32_t s_rng[2][2];        // per frame parity: [0] lowest, [1] highest entry offset of the tile's entered blocks
 	const int tid = threadIdx.x;
 	const uint32_t npx = A.w * A.h;
 	for (int i = tid; i < 512; i += DEC_T) s_pal[i] = A.pal[i];
-	__syncthreads();
 
 	const uint32_t group = blockIdx.x / A.tpf, tile = blockIdx.x - group * A.tpf;
 	const int f_lo = group == 0 ? 0 : (int)(group * 4 - A.phase);
@@ -1060,41 +1135,61 @@ __global__ __launch_bounds__(DEC_T) void k_decode(DecArgs A)
 		stale = true; istale = true;
 	}
 
-	// software pipeline over the frames of the GOP: the entry offset of frame f+1 is fetched while
-	// frame f is reconstructed
-	uint32_t off_n = valid ? A.offsets[(size_t)f_lo * A.nblk + blk] : 0u;
-	uint32_t ne_n = A.nentered[f_lo], bpos_n = A.bpos[f_lo];
-	for (int f = f_lo; f < f_hi; f++) {
-		const uint32_t ne = ne_n, off_c = off_n, bpos_c = bpos_n;
-		if (f + 1 < f_hi) {
-			off_n = valid ? A.offsets[(size_t)(f + 1) * A.nblk + blk] : 0u;
-			ne_n = A.nentered[f + 1]; bpos_n = A.bpos[f + 1];
+	// Software pipeline over the frames of the GOP, one barrier per frame.  While frame f is reconstructed out of
+	// LDS, the bytes of frame f+1 (the range the tile's entered blocks can touch: [first entry, last entry + 33 + 8];
+	// entry offsets increase with the block index) are in flight from global memory into registers, and the entry
+	// offsets of frame f+2 behind them.
+	auto publish_range = [&](int fn, uint32_t off, uint32_t ne_) {
+		if (valid && blk < ne_) {
+			if (tid == 0) s_rng[fn & 1][0] = off;
+			if (blk + 1 == ne_ || tid == DEC_T - 1 || blk + 1 == A.nblk) s_rng[fn & 1][1] = off;   // exactly one lane: the last entered one
 		}
-		bool fill_written = false;
-		// ---- stage the byte range the tile's entered blocks can touch: [first entry, last entry + 33 + 8] in ONE
-		// coalesced round trip; the dependent byte reads of decode_block then hit LDS (entry offsets increase with
-		// the block index, so the range is [offset of the first lane, offset of the last entered lane])
-		const bool entered = valid && blk < ne;
-		if (tid == 0) { s_rng[0] = off_c; s_rng[1] = off_c; }
-		__syncthreads();
-		if (entered && (blk + 1 == ne || tid == DEC_T - 1 || blk + 1 == A.nblk)) s_rng[1] = off_c;   // exactly one lane: the last entered one
-		__syncthreads();
-		const uint32_t r_lo = s_rng[0] & ~3u;
-		uint32_t r_len = s_rng[1] + 48u - r_lo;
-		if (r_len > (uint32_t)DEC_STAGE) r_len = DEC_STAGE;
-		const uint8_t* fb = A.bits + (size_t)f * A.stride;
-		if (tile * DEC_T < ne) {                               // uniform: at least the first block of the tile is entered
-			for (uint32_t i = tid * 4u; i < r_len; i += DEC_T * 4u) {
-				const uint32_t pos = r_lo + i;
-				uint32_t v = 0;
-				if (pos + 4u <= (uint32_t)A.stride) v = *(const uint32_t*)(fb + pos);
-				*(uint32_t*)(s_bytes + i) = v;
+	};
+	uint32_t st[DEC_SR];
+	auto issue_stage = [&](int fn, uint32_t ne_, uint32_t& lo, uint32_t& len) {
+		lo = 0; len = 0;
+		if (tile * DEC_T < ne_) {                              // uniform: at least the first block of the tile is entered
+			lo = s_rng[fn & 1][0] & ~3u;
+			len = s_rng[fn & 1][1] + 48u - lo;
+			if (len > (uint32_t)DEC_STAGE) len = DEC_STAGE;
+			len &= ~3u;
+			const uint8_t* fbn = A.bits + (size_t)fn * A.stride;
+#pragma unroll
+			for (int k = 0; k < DEC_SR; k++) {
+				const uint32_t i = (uint32_t)(k * DEC_T + tid) * 4u, pos = lo + i;
+				st[k] = (i < len && pos + 4u <= (uint32_t)A.stride) ? *(const uint32_t*)(fbn + pos) : 0u;
 			}
 		}
-		__syncthreads();
+	};
+	uint32_t off_n = valid ? A.offsets[(size_t)f_lo * A.nblk + blk] : 0u;
+	uint32_t ne_n = A.nentered[f_lo], bpos_n = A.bpos[f_lo];
+	uint32_t lo_n, len_n;
+	publish_range(f_lo, off_n, ne_n);
+	__syncthreads();                                           // palette + first range
+	issue_stage(f_lo, ne_n, lo_n, len_n);
+	uint32_t off_nn = (valid && f_lo + 1 < f_hi) ? A.offsets[(size_t)(f_lo + 1) * A.nblk + blk] : 0u;
+	bool anystale = false;
+	for (int f = f_lo; f < f_hi; f++) {
+		const uint32_t ne = ne_n, off_c = off_n, bpos_c = bpos_n, r_lo = lo_n, r_len = len_n;
+		const bool nextf = f + 1 < f_hi;
+		off_n = off_nn;
+		if (nextf) { ne_n = A.nentered[f + 1]; bpos_n = A.bpos[f + 1]; }
+		if (valid && f + 2 < f_hi) off_nn = A.offsets[(size_t)(f + 2) * A.nblk + blk];
+		uint8_t* sb = s_bytes[f & 1];
+#pragma unroll
+		for (int k = 0; k < DEC_SR; k++) {
+			const uint32_t i = (uint32_t)(k * DEC_T + tid) * 4u;
+			if (i < r_len) *(uint32_t*)(sb + i) = st[k];
+		}
+		if (nextf) publish_range(f + 1, off_n, ne_n);
+		// LDS-only barrier: __syncthreads() would also wait (vmcnt(0)) for the previous frame's pixel stores
+		asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+		if (nextf) issue_stage(f + 1, ne_n, lo_n, len_n);
+		bool fill_written = false;
+		const bool entered = valid && blk < ne;
 		if (entered) {
-			StagedSrc src{(const __attribute__((address_space(3))) uint8_t*)s_bytes, r_lo, r_len & ~3u, fb, (uint32_t)A.stride};
-			decode_block<M512>(src, off_c, bpos_c, s_pal, cur, icol, istale, stale, fill_written);
+			StagedSrc src{(const __attribute__((address_space(3))) uint8_t*)sb, r_lo, r_len, A.bits + (size_t)f * A.stride, (uint32_t)A.stride};
+			decode_block_staged<M512>(src, off_c, bpos_c, s_pal, cur, icol, istale, stale, fill_written);
 		}
 		if (has_last) {                                        // img_data[(x-1)+(y+1)*w] of the block to the left
 			s_nb[tid] = cur[7];
@@ -1117,13 +1212,12 @@ __global__ __launch_bounds__(DEC_T) void k_decode(DecArgs A)
 			for (int k = 0; k < 16; k++) icol[k] = cur[k];
 			istale = stale;
 		}
-		if (valid) {
-			store_block(A.out + (size_t)f * npx, poff, A.w, cur);
-			if (stale) {
-				atomicOr(A.dirty + (blk >> 5), 1u << (blk & 31u));
-				A.dirty[(A.nblk + 31) >> 5] = 1u;                   // "anything to repair" word behind the bitmap
-			}
-		}
+		anystale |= stale;
+		if (valid) store_block(A.out + (size_t)f * npx, poff, A.w, cur);
+	}
+	if (valid && anystale) {                                   // stale in any frame of the GOP: k_fixup replays the block
+		atomicOr(A.dirty + (blk >> 5), 1u << (blk & 31u));
+		A.dirty[(A.nblk + 31) >> 5] = 1u;                       // "anything to repair" word behind the bitmap
 	}
 }
 
@@ -1516,9 +1610,9 @@ extern "C" int agmv_hip_parse_frames_dev(agmv_hip_ctx* c, const uint8_t* d_bits,
 		CK(hipGetLastError());
 		return 0;
 	}
-	if ((stride & 3u) || ((uintptr_t)d_bits & 3u)) { snprintf(g_err, sizeof(g_err), "agmv_hip: bitstream slab and stride must be 4-byte aligned"); return -1; }
+	if ((stride & 3u) || stride < 4 || ((uintptr_t)d_bits & 3u)) { snprintf(g_err, sizeof(g_err), "agmv_hip: bitstream slab and stride must be 4-byte aligned"); return -1; }
 	const size_t cpf = (stride + PC) / PC, maxchunks = cpf * n_frames;
-	const size_t need = (size_t)n_frames + 1 + maxchunks + maxchunks * 33 + 16;
+	const size_t need = (size_t)n_frames + 1 + maxchunks + (maxchunks * 33 + 1) / 2 + 16;   // dwords: cum | centry | summ (u16)
 	if (need > c->parse_ws_cap) {
 		if (c->d_parse_ws) CK(hipFree(c->d_parse_ws));
 		c->d_parse_ws = nullptr; c->parse_ws_cap = 0;
@@ -1528,7 +1622,7 @@ extern "C" int agmv_hip_parse_frames_dev(agmv_hip_ctx* c, const uint8_t* d_bits,
 	ParseArgs A;
 	memset(&A, 0, sizeof(A));
 	A.bits = d_bits; A.stride = stride; A.bpos = d_bpos; A.offsets = d_offsets; A.nentered = d_nentered;
-	A.cum = c->d_parse_ws; A.centry = A.cum + n_frames + 1; A.summ = A.centry + maxchunks;
+	A.cum = c->d_parse_ws; A.centry = A.cum + n_frames + 1; A.summ = (uint16_t*)(A.centry + maxchunks);
 	A.n_frames = n_frames; A.nblk = nblk;
 	const dim3 gy(1, n_frames < 65535u ? n_frames : 65535u);
 	ev_mark(c, 2, s);
@@ -1541,13 +1635,13 @@ extern "C" int agmv_hip_parse_frames_dev(agmv_hip_ctx* c, const uint8_t* d_bits,
 	const dim3 grid(gx, gy.y);
 	hipLaunchKernelGGL(k_parse_prefix, dim3(1), dim3(64), 0, s, A);
 	CK(hipGetLastError());
-	if (c->mode512) hipLaunchKernelGGL(k_parse_chunks<true>, grid, dim3(PT), 0, s, A);
-	else            hipLaunchKernelGGL(k_parse_chunks<false>, grid, dim3(PT), 0, s, A);
+	if (c->mode512) hipLaunchKernelGGL(k_parse_chunks<true>, grid, dim3(64), 0, s, A);
+	else            hipLaunchKernelGGL(k_parse_chunks<false>, grid, dim3(64), 0, s, A);
 	CK(hipGetLastError());
 	hipLaunchKernelGGL(k_parse_stitch, dim3(n_frames), dim3(64), 0, s, A);
 	CK(hipGetLastError());
-	if (c->mode512) hipLaunchKernelGGL(k_parse_emit<true>, grid, dim3(PT), 0, s, A);
-	else            hipLaunchKernelGGL(k_parse_emit<false>, grid, dim3(PT), 0, s, A);
+	if (c->mode512) hipLaunchKernelGGL(k_parse_emit<true>, grid, dim3(64), 0, s, A);
+	else            hipLaunchKernelGGL(k_parse_emit<false>, grid, dim3(64), 0, s, A);
 	CK(hipGetLastError());
 	ev_mark(c, 3, s);
 	return 0;
@@ -1564,7 +1658,7 @@ extern "C" int agmv_hip_decode_frames_dev(agmv_hip_ctx* c, const uint8_t* d_bits
 	if (((uintptr_t)d_out & 15u) || ((uintptr_t)d_prev & 15u) || ((uintptr_t)d_prev_iframe & 15u)) {
 		snprintf(g_err, sizeof(g_err), "agmv_hip: pixel buffers must be 16-byte aligned"); return -1;
 	}
-	if ((stride & 3u) || ((uintptr_t)d_bits & 3u)) { snprintf(g_err, sizeof(g_err), "agmv_hip: bitstream slab and stride must be 4-byte aligned"); return -1; }
+	if ((stride & 3u) || stride < 4 || ((uintptr_t)d_bits & 3u)) { snprintf(g_err, sizeof(g_err), "agmv_hip: bitstream slab and stride must be 4-byte aligned"); return -1; }
 	hipStream_t s = (hipStream_t)stream;
 	DecArgs A;
 	memset(&A, 0, sizeof(A));
