@@ -223,6 +223,10 @@ int  AGMV_ResetFrameRate(const char* filename, u32 frames_per_second);
  * agmv_utils.h:114-116).  All of these run on the GPU. */
 u8 AGMV_FindNearestColor(u32 palette[256], u32 color);
 AGMV_ENTRY AGMV_FindNearestEntry(u32 palette0[256], u32 palette1[256], u32 color);
+/* unused by the library itself (reference src/agmv_utils.c:818-849, :897-914): nearest colour among the first 200
+   palette slots; the entry picks the palette with the smaller INDEX.  Host code, kept for API completeness. */
+u8 AGMV_FindSmallestColor(u32 palette[256], u32 color);
+AGMV_ENTRY AGMV_FindSmallestEntry(u32 palette0[256], u32 palette1[256], u32 color);
 u8 AGMV_ComparePFrameBlock(AGMV* agmv, u32 x, u32 y, AGMV_ENTRY* entry);
 u8 AGMV_CompareIFrameBlock(AGMV* agmv, u32 x, u32 y, u32 color, AGMV_ENTRY* img_entry);
 void AGMV_AssembleIFrameBitstream(AGMV* agmv, AGMV_ENTRY* img_entry);
@@ -258,6 +262,10 @@ void AGMV_SkipForwards(FILE* file, AGMV* agmv, int n);
 void AGMV_SkipBackwards(FILE* file, AGMV* agmv, int n);
 void AGMV_SkipTo(FILE* file, AGMV* agmv, int n);
 void AGMV_PlayAGMV(FILE* file, AGMV* agmv);
+void PlotPixel(u32* vram, int x, int y, int w, int h, u32 color);
+void AGMV_DisplayFrame(u32* vram, u16 width, u16 height, AGMV* agmv);
+/* the finished file as a C array in ./agmv.h (reference src/agmv_utils.c:1577-1615) */
+void AGMV_ExportAGMVToHeader(const char* filename);
 
 /* ---- extensions of this build (not in the reference) -------------------------------------- */
 /* frames per GPU batch of the sequence drivers (default 64; env AGMV_BATCH_FRAMES) and host

@@ -179,6 +179,17 @@ struct EncArgs {
 	uint32_t n_frames, w, h, bw, nblk, tpf, first_fc, phase, n_groups, last_iframe, total_tiles;
 };
 
+// Workgroup barrier that orders LDS only.  __syncthreads() also carries a global-memory fence, i.e. an
+// s_waitcnt vmcnt(0): every prefetch and every output store in flight would have to land before the barrier.
+__device__ __forceinline__ void lds_barrier()
+{
+#ifdef ABL_FULLBARRIER
+	__syncthreads();
+#else
+	asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#endif
+}
+
 __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t x, int lane)
 {
 #pragma unroll
@@ -422,7 +433,6 @@ __global__ __launch_bounds__(ENC_T, 4) void k_encode(EncArgs A)
 					eq[i * 4 + 3] = (uint16_t)__builtin_amdgcn_raw_buffer_load_b16(lut_rs, lut_index(px[i].w) * 2u, 0, 0);
 #endif
 				}
-				if (f + 1 < f_hi) load_frame(A.pix + (size_t)(f + 1) * npx, px);   // prefetch the next frame of the GOP
 				// [block][pixel] u16 table in the wave's scratch; a lane writes its row: 8 bytes at i*512 + lane*8
 #pragma unroll
 				for (int i = 0; i < 4; i++) {
@@ -431,6 +441,10 @@ __global__ __launch_bounds__(ENC_T, 4) void k_encode(EncArgs A)
 					q.y = eq[i * 4 + 2] | (eq[i * 4 + 3] << 16);
 					*(uint2*)(scratch + 12 + i * 512 + lane * 8) = q;      // +12: 16-byte alignment of the b128 reads below
 				}
+				// prefetch the next frame of the GOP -- pinned BEHIND the table look-ups: the memory counter retires in
+				// order, so pixel loads issued ahead of them would have to land (HBM latency) before the first entry is usable
+				asm volatile("" ::: "memory");
+				if (f + 1 < f_hi) load_frame(A.pix + (size_t)(f + 1) * npx, px);
 				__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 				__builtin_amdgcn_wave_barrier();
 				// ---- transpose: lane = block reads its 16 entries (32 contiguous bytes), kept PACKED two per register
@@ -492,7 +506,7 @@ __global__ __launch_bounds__(ENC_T, 4) void k_encode(EncArgs A)
 				uint32_t* wsum = s_misc + (f & 1) * 8;
 				const uint32_t incl = wave_incl_scan(len, lane);
 				if (lane == 63) wsum[wave] = incl;
-				__syncthreads();                                   // (A) every wave is done with its scratch slice
+				lds_barrier();                                     // (A) every wave is done with its scratch slice
 				uint32_t woff = 0;
 #pragma unroll
 				for (int i = 0; i < ENC_WAVES; i++) {
@@ -545,7 +559,7 @@ __global__ __launch_bounds__(ENC_T, 4) void k_encode(EncArgs A)
 					}
 				}
 			} else {
-				__syncthreads();                                   // keep the barrier sequence identical on the drain iteration
+				lds_barrier();                                     // keep the barrier sequence identical on the drain iteration
 			}
 
 			// ---- (L) resolve frame f-1: look-back (wave 0), then copy its stage out
@@ -567,7 +581,7 @@ __global__ __launch_bounds__(ENC_T, 4) void k_encode(EncArgs A)
 					if (tile == A.tpf - 1) A.sizes[f - 1] = excl + total_prev;   // usize of the frame
 				}
 			}
-			__syncthreads();                                       // (B) stage[f&1] written, base of f-1 known
+			lds_barrier();                                         // (B) stage[f&1] written, base of f-1 known
 #ifdef ABL_NOEMIT
 			if (have_prev && total_prev == 0xFFFFFFFFu) {
 #else
@@ -1182,8 +1196,7 @@ __global__ __launch_bounds__(DEC_T, DEC_WPE) void k_decode(DecArgs A)
 			if (i < r_len) *(uint32_t*)(sb + i) = st[k];
 		}
 		if (nextf) publish_range(f + 1, off_n, ne_n);
-		// LDS-only barrier: __syncthreads() would also wait (vmcnt(0)) for the previous frame's pixel stores
-		asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+		lds_barrier();
 		if (nextf) issue_stage(f + 1, ne_n, lo_n, len_n);
 		bool fill_written = false;
 		const bool entered = valid && blk < ne;

@@ -377,3 +377,66 @@ int AGMV_ResetFrameRate(const char* filename, u32 fps)
 	fclose(f);
 	return NO_ERR;
 }
+
+/* ---- small helpers of the reference API that nothing on the hot path calls ------------------ */
+
+/* reference src/agmv_utils.c:818-849: like AGMV_FindNearestColor but over slots 0..199 only */
+u8 AGMV_FindSmallestColor(u32 palette[256], u32 color)
+{
+	int r = AGMV_GetR(color), g = AGMV_GetG(color), b = AGMV_GetB(color), i;
+	u32 best = 3u * 255u * 255u + 1u;
+	u8 at = 0;
+	for (i = 0; i < 200; i++) {
+		int dr = r - (int)AGMV_GetR(palette[i]), dg = g - (int)AGMV_GetG(palette[i]), db = b - (int)AGMV_GetB(palette[i]);
+		u32 d = (u32)(dr * dr + dg * dg + db * db);
+		if (d < best) { best = d; at = (u8)i; }
+	}
+	return at;
+}
+
+/* reference src/agmv_utils.c:897-914: compares the two INDICES, not the distances */
+AGMV_ENTRY AGMV_FindSmallestEntry(u32 palette0[256], u32 palette1[256], u32 color)
+{
+	AGMV_ENTRY e;
+	u8 i0 = AGMV_FindSmallestColor(palette0, color), i1 = AGMV_FindSmallestColor(palette1, color);
+	memset(&e, 0, sizeof(e));
+	if (i0 <= i1) { e.index = i0; e.pal_num = 0; }
+	else { e.index = i1; e.pal_num = 1; }
+	return e;
+}
+
+/* reference src/agmv_playback.c:117-134 */
+void PlotPixel(u32* vram, int x, int y, int w, int h, u32 color)
+{
+	if (x >= 0 && y >= 0 && x < w && y < h) vram[x + y * w] = color;
+}
+
+void AGMV_DisplayFrame(u32* vram, u16 width, u16 height, AGMV* agmv)
+{
+	u32 fw = agmv->frame->width, fh = agmv->frame->height, x, y;
+	for (y = 0; y < fh; y++)
+		for (x = 0; x < fw; x++) PlotPixel(vram, (int)x, (int)y, width, height, agmv->frame->img_data[x + y * fw]);
+}
+
+/* reference src/agmv_utils.c:1577-1615: ./agmv.h with the file as `agmv_file[FILE_SIZE]`, a line break every 500 bytes */
+void AGMV_ExportAGMVToHeader(const char* filename)
+{
+	FILE *in = fopen(filename, "rb"), *out;
+	long n, i;
+	u8* data;
+	if (!in) return;
+	fseek(in, 0, SEEK_END); n = ftell(in); fseek(in, 0, SEEK_SET);
+	data = (u8*)malloc(n > 0 ? (size_t)n : 1);
+	if (!data || fread(data, 1, (size_t)n, in) != (size_t)n) { free(data); fclose(in); return; }
+	fclose(in);
+	out = fopen("agmv.h", "w");
+	if (!out) { free(data); return; }
+	fprintf(out, "#ifndef AGMV_H\n#define AGMV_H\n\n#define FILE_SIZE %ld\n\nconst unsigned char agmv_file[FILE_SIZE] = {\n", n);
+	for (i = 0; i < n; i++) {
+		if (i % 500 == 0 && i != 0) fprintf(out, "\n");
+		fprintf(out, "%d,", data[i]);
+	}
+	fprintf(out, "};\n#endif");
+	fclose(out);
+	free(data);
+}

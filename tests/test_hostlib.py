@@ -174,3 +174,59 @@ def test_palette_build_matches_reference_file(tmp_path):
         H.lib().AGMV_BuildPalette(hist, quality, opt, p0, p1)
         mine = np.concatenate([p0, p1])[:256 * npal].astype(np.uint32)
         assert (mine == ref_pal).all(), (opt, quality, int((mine != ref_pal).sum()))
+
+
+class _Entry(C.Structure):
+    _fields_ = [("pal_num", C.c_uint8), ("index", C.c_uint8), ("occurence", C.c_ulong)]
+
+
+def test_find_smallest_helpers_match_reference():
+    """AGMV_FindSmallestColor / AGMV_FindSmallestEntry (reference src/agmv_utils.c:818-849, :897-914; unused by the
+    library, part of its API): first 200 slots only, entry chosen by the smaller index."""
+    rng = np.random.default_rng(11)
+    p0 = rng.integers(0, 1 << 24, 256).astype(np.uint64)
+    p1 = rng.integers(0, 1 << 24, 256).astype(np.uint64)
+    p1[7] = p0[3]
+    cols = [int(c) for c in rng.integers(0, 1 << 24, 200)] + [int(p0[3]), int(p0[250]), 0, 0xFFFFFF]
+    libs = [C.CDLL(H.SO)] + ([C.CDLL(O.REF_SO)] if O.have_ref() else [])
+    for L in libs:
+        L.AGMV_FindSmallestColor.restype = C.c_uint8
+        L.AGMV_FindSmallestColor.argtypes = [C.c_void_p, C.c_ulong]
+        L.AGMV_FindSmallestEntry.restype = _Entry
+        L.AGMV_FindSmallestEntry.argtypes = [C.c_void_p, C.c_void_p, C.c_ulong]
+
+    def smallest(pal, c):
+        ch = lambda v, s: (v >> s) & 255
+        d = [(ch(c, 16) - ch(int(q), 16)) ** 2 + (ch(c, 8) - ch(int(q), 8)) ** 2 + (ch(c, 0) - ch(int(q), 0)) ** 2 for q in pal[:200]]
+        return int(np.argmin(d))
+
+    for c in cols:
+        want0, want1 = smallest(p0, c), smallest(p1, c)
+        want = (0, want0) if want0 <= want1 else (1, want1)
+        for L in libs:
+            assert L.AGMV_FindSmallestColor(p0.ctypes.data, c) == want0
+            e = L.AGMV_FindSmallestEntry(p0.ctypes.data, p1.ctypes.data, c)
+            assert (e.pal_num, e.index) == want
+
+
+def test_display_frame_and_header_export(tmp_path):
+    L = C.CDLL(H.SO)
+    # AGMV_ExportAGMVToHeader: ./agmv.h, byte-identical to the reference's when it is built here
+    src = tmp_path / "clip.agmv"
+    src.write_bytes(bytes(range(256)) * 5 + b"tail")
+    outs = []
+    for so in [H.SO] + ([O.REF_SO] if O.have_ref() else []):
+        d = tmp_path / ("o%d" % len(outs))
+        d.mkdir()
+        code = "import ctypes,os;os.chdir(%r);L=ctypes.CDLL(%r);L.AGMV_ExportAGMVToHeader(%r)" % (str(d), so, str(src).encode())
+        assert os.system("%s -c %r" % (os.sys.executable, code)) == 0
+        outs.append((d / "agmv.h").read_bytes())
+    assert outs[0].startswith(b"#ifndef AGMV_H\n#define AGMV_H\n\n#define FILE_SIZE 1284\n\nconst unsigned char agmv_file[FILE_SIZE] = {\n0,1,2,")
+    assert outs[0].count(b"\n") == 6 + 2 + 1 and outs[0].endswith(b"116,97,105,108,};\n#endif")
+    assert all(o == outs[0] for o in outs)
+    # PlotPixel clips; AGMV_DisplayFrame copies the frame into the top-left of a larger (or smaller) target
+    L.PlotPixel.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_ulong]
+    vram = np.zeros(6 * 4, np.uint64)
+    for (x, y) in ((-1, 0), (0, -1), (6, 0), (0, 4), (5, 3), (2, 1)):
+        L.PlotPixel(vram.ctypes.data, x, y, 6, 4, 0xABCDEF)
+    assert sorted(np.nonzero(vram)[0].tolist()) == [2 + 6, 5 + 18]
