@@ -725,6 +725,7 @@ __device__ __forceinline__ void wave_lds_sync()
 template <int NLV>
 struct ParseLds {
 	uint8_t b[PC + PHALO];                  // staged bytes
+	unsigned long long esc[PNSEG + 2];      // per 64 bytes (chunk + halo): which bytes are escape codes ((b & 0x7f) == 127)
 	uint16_t rank_at[PC];                   // position -> nodes before it = index of the first node at or after it
 	uint16_t npos[PC];                      // node -> position in the chunk
 	uint16_t jl[NLV][PC];                   // node -> jump target (node index | J_EXIT+offset | J_END)
@@ -756,6 +757,14 @@ __device__ __forceinline__ uint32_t parse_chunk_nodes(ParseLds<NLV>& S, uint16_t
 		S.rank_at[p] = (uint16_t)r;
 		if (node) S.npos[r] = (uint16_t)p;
 		mtot += (uint32_t)__popcll(m);
+		if (M512) {
+			const unsigned long long em = __ballot((by[sg] & 0x7fu) == 127u);
+			if (lane == 0) S.esc[sg] = em;
+		}
+	}
+	if (M512) {
+		const unsigned long long em = __ballot((S.b[PC + lane] & 0x7fu) == 127u);    // the halo
+		if (lane == 0) { S.esc[PNSEG] = em; S.esc[PNSEG + 1] = 0; }
 	}
 	wave_lds_sync();
 	// ---- one lane per node: where its block ends, and the node that follows
@@ -766,8 +775,14 @@ __device__ __forceinline__ uint32_t parse_chunk_nodes(ParseLds<NLV>& S, uint16_t
 		if (byte == FILL_FLAG) e += M512 ? 1u + ((S.b[p + 1] & 0x7fu) == 127u ? 1u : 0u) : 1u;
 		else if (byte == NORMAL_FLAG) {
 			if (M512) {
-#pragma unroll 4
-				for (int i = 0; i < 16; i++) e += 1u + ((S.b[e] & 0x7fu) == 127u ? 1u : 0u);
+				// 16 codes of 1 or 2 bytes: the escape bits of the 32 bytes behind the flag, walked in registers
+				const uint32_t sg = e >> 6, sh = e & 63u;
+				const unsigned long long lo = S.esc[sg], hi = S.esc[sg + 1];
+				const uint32_t m = (uint32_t)(sh ? (lo >> sh) | (hi << (64u - sh)) : lo);
+				uint32_t pos = 0;
+#pragma unroll
+				for (int i = 0; i < 16; i++) pos += 1u + ((m >> pos) & 1u);
+				e += pos;
 			} else e += 16u;
 		}
 		uint32_t j = J_END, n = 0;
@@ -799,30 +814,29 @@ __global__ __launch_bounds__(64) void k_parse_chunks(ParseArgs A)
 	for (uint32_t c = blockIdx.x, g0 = A.cum[f], nch = A.cum[f + 1] - g0; c < nch; c += gridDim.x) {
 		const uint32_t g = g0 + c, cs = c * PC, bpos = A.bpos[f];
 		const uint32_t mtot = parse_chunk_nodes<M512>(S, nullptr, nn[0], nullptr, A.bits + (size_t)f * A.stride, (uint32_t)A.stride, bpos, cs, lane);
-		// ---- pointer doubling over the node list until every chain has left the chunk
-		uint32_t lv = 0;
-		for (; lv < (uint32_t)PLV; lv++) {
-			const uint16_t *js = S.jl[lv & 1u], *ns = nn[lv & 1u];
-			uint16_t *jd = S.jl[(lv + 1u) & 1u], *nd = nn[(lv + 1u) & 1u];
-			bool active = false;
+		// ---- PEL rounds of pointer doubling over the node list (jump + blocks counted along it), then the 33 entry
+		// lanes walk their chains 2^PEL nodes at a time
+#pragma unroll
+		for (int lv = 0; lv < PEL; lv++) {
+			const uint16_t *js = S.jl[lv & 1], *ns = nn[lv & 1];
+			uint16_t *jd = S.jl[(lv + 1) & 1], *nd = nn[(lv + 1) & 1];
 			for (uint32_t k = lane; k < mtot; k += 64) {
 				uint32_t j = js[k], n = ns[k];
-				if (j < J_EXIT) { n += ns[j]; j = js[j]; active |= j < J_EXIT; }
+				if (j < J_EXIT) { n += ns[j]; j = js[j]; }
 				jd[k] = (uint16_t)j;
 				nd[k] = (uint16_t)n;
 			}
 			wave_lds_sync();
-			if (!__ballot(active)) { lv++; break; }
 		}
 		if (lane < 33) {
 			uint32_t ex = X_END, cnt = 0;
 			if (cs + lane <= bpos) {
-				const uint32_t k0 = S.rank_at[lane];
-				if (k0 >= mtot) { if (cs + PC <= bpos) ex = 0; }
+				uint32_t k = S.rank_at[lane];
+				if (k >= mtot) { if (cs + PC <= bpos) ex = 0; }
 				else {
-					const uint32_t j = S.jl[lv & 1u][k0];
-					cnt = nn[lv & 1u][k0];
-					if (j != J_END) ex = j & 0x3Fu;
+					const uint16_t *jf = S.jl[PEL & 1], *nf = nn[PEL & 1];
+					do { cnt += nf[k]; k = jf[k]; } while (k < J_EXIT);
+					if (k != J_END) ex = k & 0x3Fu;
 				}
 			}
 			A.summ[(size_t)g * 33 + lane] = (uint16_t)(ex << 10 | cnt);
