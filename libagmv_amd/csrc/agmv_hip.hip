@@ -731,17 +731,29 @@ struct ParseLds {
 	uint16_t jl[NLV][PC];                   // node -> jump target (node index | J_EXIT+offset | J_END)
 };
 
+constexpr int PCD = ((PC + PHALO) / 4 + 63) / 64;      // dwords of a chunk (+halo) per lane
+
+// the chunk's bytes, dword-wide (cs and the slab stride are multiples of 4); bytes past the slab read as 0
+__device__ __forceinline__ void load_chunk(uint32_t (&raw)[PCD], const uint8_t* fbits, uint32_t cap, uint32_t cs, int lane)
+{
+#pragma unroll
+	for (int q = 0; q < PCD; q++) {
+		const uint32_t pos = cs + 4u * (uint32_t)(q * 64 + lane);
+		raw[q] = (q * 64 + lane < (PC + PHALO) / 4 && pos < cap) ? *(const uint32_t*)(fbits + pos) : 0u;
+	}
+}
+
 // Build the node list of chunk [cs, cs+PC): rank_at, npos, and per node the end of its block (eo, bit 15 = the
 // block counts, i.e. the next one starts inside the stream) and its successor (jl[0]).  Returns the node count.
 template <bool M512, int NLV>
 __device__ __forceinline__ uint32_t parse_chunk_nodes(ParseLds<NLV>& S, uint16_t* eo, uint16_t* n0, uint8_t* mark,
-                                                      const uint8_t* fbits, uint32_t cap, uint32_t bpos, uint32_t cs, int lane)
+                                                      const uint32_t (&raw)[PCD], uint32_t bpos, uint32_t cs, int lane)
 {
-	// ---- stage the chunk (+halo), dword-wide (cs and the slab stride are multiples of 4)
+	// ---- stage the chunk (+halo) the caller fetched (load_chunk) while the previous chunk was being parsed
 #pragma unroll
-	for (int i = lane; i < (PC + PHALO) / 4; i += 64) {
-		const uint32_t pos = cs + 4u * i;
-		((uint32_t*)S.b)[i] = pos < cap ? *(const uint32_t*)(fbits + pos) : 0u;
+	for (int q = 0; q < PCD; q++) {
+		const int i = q * 64 + lane;
+		if (i < (PC + PHALO) / 4) ((uint32_t*)S.b)[i] = raw[q];
 	}
 	wave_lds_sync();
 	// ---- nodes = flag-valued bytes at positions <= bpos, ranked by ballot + popcount
@@ -810,10 +822,18 @@ __global__ __launch_bounds__(64) void k_parse_chunks(ParseArgs A)
 	__shared__ uint16_t nn[2][PC];                             // node -> blocks counted along its jump (ping-pong)
 	const int lane = threadIdx.x;
 	// 2-D grid: y strides over frames, x over the chunks of a frame (no search for the frame of a chunk)
-	for (uint32_t f = blockIdx.y; f < A.n_frames; f += gridDim.y)
-	for (uint32_t c = blockIdx.x, g0 = A.cum[f], nch = A.cum[f + 1] - g0; c < nch; c += gridDim.x) {
-		const uint32_t g = g0 + c, cs = c * PC, bpos = A.bpos[f];
-		const uint32_t mtot = parse_chunk_nodes<M512>(S, nullptr, nn[0], nullptr, A.bits + (size_t)f * A.stride, (uint32_t)A.stride, bpos, cs, lane);
+	for (uint32_t f = blockIdx.y; f < A.n_frames; f += gridDim.y) {
+	const uint32_t g0 = A.cum[f], nch = A.cum[f + 1] - g0, bpos = A.bpos[f];
+	const uint8_t* fbits = A.bits + (size_t)f * A.stride;
+	uint32_t nxt[PCD];
+	if (blockIdx.x < nch) load_chunk(nxt, fbits, (uint32_t)A.stride, blockIdx.x * PC, lane);
+	for (uint32_t c = blockIdx.x; c < nch; c += gridDim.x) {
+		const uint32_t g = g0 + c, cs = c * PC;
+		uint32_t raw[PCD];
+#pragma unroll
+		for (int q = 0; q < PCD; q++) raw[q] = nxt[q];
+		if (c + gridDim.x < nch) load_chunk(nxt, fbits, (uint32_t)A.stride, (c + gridDim.x) * PC, lane);   // in flight over this chunk
+		const uint32_t mtot = parse_chunk_nodes<M512>(S, nullptr, nn[0], nullptr, raw, bpos, cs, lane);
 		// ---- PEL rounds of pointer doubling over the node list (jump + blocks counted along it), then the 33 entry
 		// lanes walk their chains 2^PEL nodes at a time
 #pragma unroll
@@ -842,6 +862,7 @@ __global__ __launch_bounds__(64) void k_parse_chunks(ParseArgs A)
 			A.summ[(size_t)g * 33 + lane] = (uint16_t)(ex << 10 | cnt);
 		}
 		wave_lds_sync();
+	}
 	}
 }
 
@@ -888,16 +909,26 @@ __global__ __launch_bounds__(64) void k_parse_emit(ParseArgs A)
 	__shared__ uint16_t eo[PC];                                // node -> end of its block (chunk-relative, <= PC+32) | counts << 15
 	__shared__ uint8_t mark[PC];
 	const int lane = threadIdx.x;
-	for (uint32_t f = blockIdx.y; f < A.n_frames; f += gridDim.y)
-	for (uint32_t c = blockIdx.x, g0 = A.cum[f], nch = A.cum[f + 1] - g0; c < nch; c += gridDim.x) {
-		const uint32_t g = g0 + c;
-		const uint32_t ce = A.centry[g], o = ce & 0xFFu, kb = ce >> 8;
-		uint32_t* off = A.offsets + (size_t)f * A.nblk;
+	for (uint32_t f = blockIdx.y; f < A.n_frames; f += gridDim.y) {
+	const uint32_t g0 = A.cum[f], nch = A.cum[f + 1] - g0, bpos = A.bpos[f];
+	const uint8_t* fbits = A.bits + (size_t)f * A.stride;
+	uint32_t* off = A.offsets + (size_t)f * A.nblk;
+	uint32_t nxt[PCD], ce_n = 0;
+	if (blockIdx.x < nch) { ce_n = A.centry[g0 + blockIdx.x]; load_chunk(nxt, fbits, (uint32_t)A.stride, blockIdx.x * PC, lane); }
+	for (uint32_t c = blockIdx.x; c < nch; c += gridDim.x) {
+		const uint32_t ce = ce_n, o = ce & 0xFFu, kb = ce >> 8;
+		uint32_t raw[PCD];
+#pragma unroll
+		for (int q = 0; q < PCD; q++) raw[q] = nxt[q];
+		if (c + gridDim.x < nch) {                             // next chunk: in flight over this one
+			ce_n = A.centry[g0 + c + gridDim.x];
+			load_chunk(nxt, fbits, (uint32_t)A.stride, (c + gridDim.x) * PC, lane);
+		}
 		if (c == 0 && lane == 0) off[0] = 0;                   // block 0 is entered at byte 0
 		if (o == 0xFFu) continue;                              // the chain ended before this chunk (uniform)
 		if (kb + 1u >= A.nblk) continue;                       // every block this chunk could enter is beyond the frame
-		const uint32_t cs = c * PC, bpos = A.bpos[f];
-		const uint32_t mtot = parse_chunk_nodes<M512>(S, eo, nullptr, mark, A.bits + (size_t)f * A.stride, (uint32_t)A.stride, bpos, cs, lane);
+		const uint32_t cs = c * PC;
+		const uint32_t mtot = parse_chunk_nodes<M512>(S, eo, nullptr, mark, raw, bpos, cs, lane);
 		const uint32_t k0 = cs + o <= bpos ? S.rank_at[o] : mtot;
 		if (k0 < mtot) {
 			// PEL rounds of pointer doubling, then one lane walks the true chain 2^PEL nodes at a time and the kept
@@ -936,6 +967,7 @@ __global__ __launch_bounds__(64) void k_parse_emit(ParseArgs A)
 			}
 		}
 		wave_lds_sync();
+	}
 	}
 }
 
