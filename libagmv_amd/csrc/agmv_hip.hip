@@ -281,25 +281,29 @@ constexpr size_t CTRL_BYTES = 16;                              // [0] ticket, [1
 
 // copy staged bytes [lo, hi) of a tile to the frame bitstream (gdst = address of staged byte 0), one wave:
 // dword stores on global-aligned dwords (staged byte i lives at stage byte 4+i), bytes at the ragged ends.
-__device__ __forceinline__ void wave_copy_out(const uint8_t* stage, uint8_t* gdst, uint32_t lo, uint32_t hi, int lane)
+__device__ __forceinline__ void wave_copy_out(const uint8_t* stage, uint8_t* gdst, uint32_t total, int wave, int lane)
 {
-	if (lo >= hi) return;
-	uint8_t* g = gdst + lo;
-	const uint32_t total = hi - lo;
-	const uint32_t s = (uint32_t)((uintptr_t)g & 3u);
-	uint8_t* g0 = g - s;
-	const uint32_t ndw = (s + total + 3u) >> 2;
-	const uint32_t* s32 = (const uint32_t*)(stage + lo);      // lo is a multiple of 4
-	for (uint32_t j = lane; j < ndw; j += 64) {
-		const int lo_i = (int)(4u * j) - (int)s;
-		if (lo_i >= 0 && (uint32_t)lo_i + 4u <= total) {
-			const uint32_t a = s32[j], b = s32[j + 1];
-			*(uint32_t*)(g0 + 4u * j) = s ? __builtin_amdgcn_alignbyte(b, a, 4u - s) : b;
+	// The tile's bytes [0,total) sit at stage+4; the workgroup writes them to gdst as GLOBAL-aligned dwords.  Wave w
+	// writes the dwords whose first byte lies in its slice [w*WSLICE, (w+1)*WSLICE): a dword that straddles the
+	// slice end reads <= 3 bytes of the next slice, which that wave's transposes never overwrite (they start 12
+	// bytes in).  Only the tile's first and last dword can be partial (byte stores).
+	const uint32_t lo = (uint32_t)wave * WSLICE;
+	if (lo >= total) return;
+	const uint32_t hi = lo + WSLICE < total ? lo + WSLICE : total;
+	const uint32_t s = (uint32_t)((uintptr_t)gdst & 3u);
+	uint8_t* g0 = gdst - s;
+	const uint32_t d_lo = wave == 0 ? 0u : (lo + s + 3u) >> 2, d_hi = (hi + s + 3u) >> 2;
+	const uint32_t* s32 = (const uint32_t*)stage;
+	for (uint32_t d = d_lo + lane; d < d_hi; d += 64) {
+		const int t0 = (int)(4u * d) - (int)s;                 // tile byte held by the dword's first byte
+		if (t0 >= 0 && (uint32_t)t0 + 4u <= total) {
+			const uint32_t a = s32[d], b = s32[d + 1];
+			*(uint32_t*)(g0 + 4u * d) = s ? __builtin_amdgcn_alignbyte(b, a, 4u - s) : b;
 		} else {
 #pragma unroll
 			for (int q = 0; q < 4; q++) {
-				const int i = lo_i + q;
-				if (i >= 0 && (uint32_t)i < total) g0[4u * j + q] = stage[4 + lo + i];
+				const int t = t0 + q;
+				if (t >= 0 && (uint32_t)t < total) g0[4u * d + q] = stage[4 + t];
 			}
 		}
 	}
@@ -588,8 +592,10 @@ __global__ __launch_bounds__(ENC_T, 4) void k_encode(EncArgs A)
 			if (have_prev) {
 #endif
 				const uint32_t base = s_misc[16 + ((f - 1) & 1)];
-				const uint32_t lo = wave * WSLICE, hi = lo + WSLICE < total_prev ? lo + WSLICE : total_prev;
-				wave_copy_out(s_stage0 + ((f - 1) & 1) * STAGE_SZ, A.out + (size_t)(f - 1) * A.out_stride + base, lo, hi, lane);
+#ifdef ABL_NOCOPYOUT
+				if (base == 0xFFFFFFF0u)
+#endif
+				wave_copy_out(s_stage0 + ((f - 1) & 1) * STAGE_SZ, A.out + (size_t)(f - 1) * A.out_stride + base, total_prev, wave, lane);
 			}
 			total_prev = total;
 		}
