@@ -53,7 +53,10 @@ constexpr int ENC_T = 512;          // threads per encode workgroup = 4x4 blocks
 constexpr int ENC_WAVES = ENC_T / 64;
 constexpr int MROW = 17;            // dwords per matrix row: 16 used + 1 pad (LDS bank spread)
 constexpr int DEC_T = 256;          // threads per decode workgroup
-constexpr int DEC_STAGE = DEC_T * 28;   // LDS window for a tile's bitstream bytes, double-buffered (28 B per block; beyond it bytes come from global memory)
+#ifndef DEC_BPB
+#define DEC_BPB 24
+#endif
+constexpr int DEC_STAGE = DEC_T * DEC_BPB;   // LDS window for a tile's bitstream bytes in ONE frame (24 B per block; beyond it bytes come from global memory); x4 frames = 24 KB, 5 workgroups per CU
 constexpr int DEC_SR = DEC_STAGE / 4 / DEC_T;   // dwords of the window each lane carries from global memory to LDS
 constexpr uint32_t LUT_ENTRIES = 1u << 24;
 
@@ -1149,21 +1152,29 @@ __device__ __forceinline__ void store_block(uint32_t* frame, uint32_t poff, uint
 	}
 }
 
-// K3: one lane = one 4x4 block carried through the frames of its GOP (img_data and
+// K3: one lane = one 4x4 block carried through the <=4 frames of its GOP (img_data and
 // iframe->img_data of the block live in registers).  A block whose value depends on a frame
 // outside the GOP (not rewritten since the GOP started) is flagged in `dirty` and repaired by
 // k_fixup; everything else is final.
-template <bool M512>
+//
+// Everything the GOP needs is loaded UP FRONT, in two dependent round trips: (1) the block's entry offset in each
+// of the four frames (+ nentered/bpos, palette, previous state), (2) after the workgroup has exchanged the byte
+// range its entered blocks span in each frame, the four byte windows into a quad-buffered LDS stage.  The frame
+// loop then reads LDS only -- no global load, no wait on the vector-memory counter, no barrier (except the last
+// tile's neighbour exchange) -- so the 64 B/lane pixel stores of one frame drain while the next is reconstructed.
+// (A wave's memory counter retires in order: with per-frame staging every wait for the next frame's bytes also
+// waited for the previous frame's stores, and under saturating writes those round trips take 2-3 us.)
 #ifndef DEC_WPE
-#define DEC_WPE 4
+#define DEC_WPE 5         // waves per SIMD: 87 VGPRs, no spills; 6 spills and is slower
 #endif
+template <bool M512>
 __global__ __launch_bounds__(DEC_T, DEC_WPE) void k_decode(DecArgs A)
 {
 	__shared__ uint32_t s_pal[512];
 	__shared__ uint32_t s_nb[DEC_T];        // neighbour exchange for the last-block quirk
 	__shared__ uint32_t s_nbstale[DEC_T];
-	__shared__ __attribute__((aligned(16))) uint8_t s_bytes[2][DEC_STAGE];   // this tile's slice of the frame's bitstream (frame parity)
-	__shared__ uint32_t s_rng[2][2];        // per frame parity: [0] lowest, [1] highest entry offset of the tile's entered blocks
+	__shared__ __attribute__((aligned(16))) uint8_t s_bytes[4][DEC_STAGE];   // the tile's slice of each frame's bitstream
+	__shared__ uint32_t s_rng[4][2];        // per frame: [0] lowest, [1] highest entry offset of the tile's entered blocks
 	const int tid = threadIdx.x;
 	const uint32_t npx = A.w * A.h;
 	for (int i = tid; i < 512; i += DEC_T) s_pal[i] = A.pal[i];
@@ -1172,6 +1183,7 @@ __global__ __launch_bounds__(DEC_T, DEC_WPE) void k_decode(DecArgs A)
 	const int f_lo = group == 0 ? 0 : (int)(group * 4 - A.phase);
 	int f_hi = (int)(group * 4 - A.phase) + 4;
 	if (f_hi > (int)A.n_frames) f_hi = (int)A.n_frames;
+	const int nf = f_hi - f_lo;                                // 1..4 frames
 
 	const uint32_t blk = tile * DEC_T + tid;
 	const bool valid = blk < A.nblk;
@@ -1181,6 +1193,14 @@ __global__ __launch_bounds__(DEC_T, DEC_WPE) void k_decode(DecArgs A)
 	const bool has_last = (tile == A.tpf - 1);                 // this workgroup holds block nblk-1
 	const bool is_last = valid && blk == A.nblk - 1;
 
+	// ---- round trip 1: entry offsets, nentered, bpos of every frame of the GOP; previous state of the block
+	uint32_t off[4], ne[4], bp[4];
+#pragma unroll
+	for (int i = 0; i < 4; i++) {
+		const int fi = i < nf ? f_lo + i : f_hi - 1;
+		off[i] = A.offsets[(size_t)fi * A.nblk + b];
+		ne[i] = A.nentered[fi]; bp[i] = A.bpos[fi];
+	}
 	uint32_t cur[16], icol[16];
 	bool stale, istale;
 	if (group == 0) {                                          // state of the decoder before the batch
@@ -1200,66 +1220,65 @@ __global__ __launch_bounds__(DEC_T, DEC_WPE) void k_decode(DecArgs A)
 		for (int k = 0; k < 16; k++) { cur[k] = 0; icol[k] = 0; }
 		stale = true; istale = true;
 	}
-
-	// Software pipeline over the frames of the GOP, one barrier per frame.  While frame f is reconstructed out of
-	// LDS, the bytes of frame f+1 (the range the tile's entered blocks can touch: [first entry, last entry + 33 + 8];
-	// entry offsets increase with the block index) are in flight from global memory into registers, and the entry
-	// offsets of frame f+2 behind them.
-	auto publish_range = [&](int fn, uint32_t off, uint32_t ne_) {
-		if (valid && blk < ne_) {
-			if (tid == 0) s_rng[fn & 1][0] = off;
-			if (blk + 1 == ne_ || tid == DEC_T - 1 || blk + 1 == A.nblk) s_rng[fn & 1][1] = off;   // exactly one lane: the last entered one
+	// the range the tile's entered blocks can touch in frame i: [first entry, last entry + 33 + 8]; entry offsets
+	// increase with the block index, so it is [offset of lane 0, offset of the last entered lane]
+#pragma unroll
+	for (int i = 0; i < 4; i++) {
+		if (i < nf && valid && blk < ne[i]) {
+			if (tid == 0) s_rng[i][0] = off[i];
+			if (blk + 1 == ne[i] || tid == DEC_T - 1 || blk + 1 == A.nblk) s_rng[i][1] = off[i];   // exactly one lane
 		}
-	};
-	uint32_t st[DEC_SR];
-	auto issue_stage = [&](int fn, uint32_t ne_, uint32_t& lo, uint32_t& len) {
-		lo = 0; len = 0;
-		if (tile * DEC_T < ne_) {                              // uniform: at least the first block of the tile is entered
-			lo = s_rng[fn & 1][0] & ~3u;
-			len = s_rng[fn & 1][1] + 48u - lo;
+	}
+	__syncthreads();                                           // ranges (and the palette) visible
+	// ---- round trip 2: the four byte windows, all in flight together
+	uint32_t r_lo[4], r_len[4];
+#pragma unroll
+	for (int i = 0; i < 4; i++) {
+		r_lo[i] = 0; r_len[i] = 0;
+		if (i < nf && tile * DEC_T < ne[i]) {                  // uniform: at least the first block of the tile is entered
+			r_lo[i] = s_rng[i][0] & ~3u;
+			uint32_t len = s_rng[i][1] + 48u - r_lo[i];
 			if (len > (uint32_t)DEC_STAGE) len = DEC_STAGE;
-			len &= ~3u;
-			const uint8_t* fbn = A.bits + (size_t)fn * A.stride;
+			r_len[i] = len & ~3u;
+		}
+	}
+	{
+		uint32_t st[4][DEC_SR];
+#pragma unroll
+		for (int i = 0; i < 4; i++) {
+			const uint8_t* fb = A.bits + (size_t)(i < nf ? f_lo + i : f_lo) * A.stride;
 #pragma unroll
 			for (int k = 0; k < DEC_SR; k++) {
-				const uint32_t i = (uint32_t)(k * DEC_T + tid) * 4u, pos = lo + i;
-				st[k] = (i < len && pos + 4u <= (uint32_t)A.stride) ? *(const uint32_t*)(fbn + pos) : 0u;
+				const uint32_t j = (uint32_t)(k * DEC_T + tid) * 4u, pos = r_lo[i] + j;
+				st[i][k] = (j < r_len[i] && pos + 4u <= (uint32_t)A.stride) ? *(const uint32_t*)(fb + pos) : 0u;
 			}
 		}
-	};
-	uint32_t off_n = valid ? A.offsets[(size_t)f_lo * A.nblk + blk] : 0u;
-	uint32_t ne_n = A.nentered[f_lo], bpos_n = A.bpos[f_lo];
-	uint32_t lo_n, len_n;
-	publish_range(f_lo, off_n, ne_n);
-	__syncthreads();                                           // palette + first range
-	issue_stage(f_lo, ne_n, lo_n, len_n);
-	uint32_t off_nn = (valid && f_lo + 1 < f_hi) ? A.offsets[(size_t)(f_lo + 1) * A.nblk + blk] : 0u;
-	bool anystale = false;
-	for (int f = f_lo; f < f_hi; f++) {
-		const uint32_t ne = ne_n, off_c = off_n, bpos_c = bpos_n, r_lo = lo_n, r_len = len_n;
-		const bool nextf = f + 1 < f_hi;
-		off_n = off_nn;
-		if (nextf) { ne_n = A.nentered[f + 1]; bpos_n = A.bpos[f + 1]; }
-		if (valid && f + 2 < f_hi) off_nn = A.offsets[(size_t)(f + 2) * A.nblk + blk];
-		uint8_t* sb = s_bytes[f & 1];
 #pragma unroll
-		for (int k = 0; k < DEC_SR; k++) {
-			const uint32_t i = (uint32_t)(k * DEC_T + tid) * 4u;
-			if (i < r_len) *(uint32_t*)(sb + i) = st[k];
+		for (int i = 0; i < 4; i++) {
+#pragma unroll
+			for (int k = 0; k < DEC_SR; k++) {
+				const uint32_t j = (uint32_t)(k * DEC_T + tid) * 4u;
+				if (j < r_len[i]) *(uint32_t*)(s_bytes[i] + j) = st[i][k];
+			}
 		}
-		if (nextf) publish_range(f + 1, off_n, ne_n);
-		lds_barrier();
-		if (nextf) issue_stage(f + 1, ne_n, lo_n, len_n);
+	}
+	__syncthreads();                                           // the last wait on global loads in this kernel
+
+	bool anystale = false;
+#pragma unroll
+	for (int i = 0; i < 4; i++) {
+		if (i >= nf) break;
+		const int f = f_lo + i;
 		bool fill_written = false;
-		const bool entered = valid && blk < ne;
+		const bool entered = valid && blk < ne[i];
 		if (entered) {
-			StagedSrc src{(const __attribute__((address_space(3))) uint8_t*)sb, r_lo, r_len, A.bits + (size_t)f * A.stride, (uint32_t)A.stride};
-			decode_block_staged<M512>(src, off_c, bpos_c, s_pal, cur, icol, istale, stale, fill_written);
+			StagedSrc src{(const __attribute__((address_space(3))) uint8_t*)s_bytes[i], r_lo[i], r_len[i], A.bits + (size_t)f * A.stride, (uint32_t)A.stride};
+			decode_block_staged<M512>(src, off[i], bp[i], s_pal, cur, icol, istale, stale, fill_written);
 		}
 		if (has_last) {                                        // img_data[(x-1)+(y+1)*w] of the block to the left
 			s_nb[tid] = cur[7];
 			s_nbstale[tid] = stale ? 1u : 0u;
-			__syncthreads();
+			lds_barrier();
 			if (is_last && fill_written) {
 				if (tid > 0) {
 					uint32_t c = s_nb[tid - 1];
@@ -1270,7 +1289,7 @@ __global__ __launch_bounds__(DEC_T, DEC_WPE) void k_decode(DecArgs A)
 					stale = true;                              // neighbour lives in another tile: fix-up
 				}
 			}
-			__syncthreads();
+			lds_barrier();
 		}
 		if (((A.first_fc + f) & 3u) == 0) {                    // I-frame snapshot, :401-405
 #pragma unroll
