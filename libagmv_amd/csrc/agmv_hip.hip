@@ -1460,9 +1460,23 @@ __device__ __forceinline__ uint32_t quantize_color(uint32_t c, int quality)
 __global__ __launch_bounds__(256) void k_histogram(const uint32_t* __restrict__ pix, size_t n, int quality,
                                                    uint32_t* __restrict__ hist)
 {
-	size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+	// lanes hold consecutive pixels; neighbours mostly fall into the same bin, so each RUN of equal codes inside the
+	// wave adds its length with one atomic (flat or static areas: one atomic per 64 pixels)
+	const int lane = threadIdx.x & 63;
 	const size_t stride = (size_t)gridDim.x * 256;
-	for (; i < n; i += stride) atomicAdd(hist + quantize_color(pix[i], quality), 1u);
+	for (size_t i0 = (size_t)blockIdx.x * 256 + (threadIdx.x & ~63); i0 < n; i0 += stride) {
+		const size_t i = i0 + lane;
+		const bool live = i < n;
+		const uint32_t c = live ? quantize_color(pix[i], quality) : 0xFFFFFFFFu;
+		const uint32_t prev = __shfl_up(c, 1, 64);
+		const bool leader = live && (lane == 0 || c != prev);
+		const unsigned long long lead = __ballot(leader), alive = __ballot(live);
+		if (leader) {
+			const unsigned long long rest = lane == 63 ? 0ull : lead >> (lane + 1);
+			const uint32_t end = rest ? (uint32_t)lane + 1u + (uint32_t)__builtin_ctzll(rest) : (uint32_t)__popcll(alive);
+			atomicAdd(hist + c, end - (uint32_t)lane);
+		}
+	}
 }
 
 // ----------------------------------------------------------------------------------------------
