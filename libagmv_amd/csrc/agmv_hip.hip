@@ -692,7 +692,11 @@ __global__ __launch_bounds__(64) void k_parse_serial(const uint8_t* __restrict__
 constexpr int PC = 512;         // bytes per chunk (one wave)
 constexpr int PNSEG = PC / 64;  // ballot segments per chunk
 constexpr int PLV = 9;          // doubling levels: 2^9 >= nodes in a chunk
-constexpr int PEL = 3;          // k_parse_emit: levels kept for marking; the chain is walked 2^PEL nodes at a time
+#ifndef PEL_OVERRIDE
+#define PEL_OVERRIDE 3
+#endif
+constexpr int PCL = 3;          // k_parse_chunks: doubling rounds before the 33 entry lanes walk 2^PCL nodes at a time
+constexpr int PEL = PEL_OVERRIDE;   // k_parse_emit: levels kept for marking; the chain is walked 2^PEL nodes at a time
 constexpr int PHALO = 64;       // bytes staged beyond the chunk (a block spans <= 33)
 constexpr uint32_t J_EXIT = 0x8000u;    // jump leaves the chunk: J_EXIT | offset into the next chunk
 constexpr uint32_t J_END = 0xFFFFu;     // chain left the readable stream (position > bpos)
@@ -731,12 +735,13 @@ __device__ __forceinline__ void wave_lds_sync()
 }
 
 // LDS of one wave's chunk.  NLV jump tables: 2 (ping-pong, k_parse_chunks) or PEL+1 (kept levels, k_parse_emit).
+// The two tables that only the node build needs (rank_at: position -> nodes before it = index of the first node at
+// or after it; npos: node -> position) are not members: the caller lends them the space of tables that are first
+// written after the build (4.75 KB / 5.75 KB per wave instead of 6.8 / 8.3: 33 / 27 waves per CU instead of 23 / 19).
 template <int NLV>
 struct ParseLds {
 	uint8_t b[PC + PHALO];                  // staged bytes
 	unsigned long long esc[PNSEG + 2];      // per 64 bytes (chunk + halo): which bytes are escape codes ((b & 0x7f) == 127)
-	uint16_t rank_at[PC];                   // position -> nodes before it = index of the first node at or after it
-	uint16_t npos[PC];                      // node -> position in the chunk
 	uint16_t jl[NLV][PC];                   // node -> jump target (node index | J_EXIT+offset | J_END)
 };
 
@@ -755,7 +760,7 @@ __device__ __forceinline__ void load_chunk(uint32_t (&raw)[PCD], const uint8_t* 
 // Build the node list of chunk [cs, cs+PC): rank_at, npos, and per node the end of its block (eo, bit 15 = the
 // block counts, i.e. the next one starts inside the stream) and its successor (jl[0]).  Returns the node count.
 template <bool M512, int NLV>
-__device__ __forceinline__ uint32_t parse_chunk_nodes(ParseLds<NLV>& S, uint16_t* eo, uint16_t* n0, uint8_t* mark,
+__device__ __forceinline__ uint32_t parse_chunk_nodes(ParseLds<NLV>& S, uint16_t* rank_at, uint16_t* npos, uint16_t* eo, uint16_t* n0,
                                                       const uint32_t (&raw)[PCD], uint32_t bpos, uint32_t cs, int lane)
 {
 	// ---- stage the chunk (+halo) the caller fetched (load_chunk) while the previous chunk was being parsed
@@ -775,8 +780,8 @@ __device__ __forceinline__ uint32_t parse_chunk_nodes(ParseLds<NLV>& S, uint16_t
 		const bool node = is_flag(by[sg]) && cs + p <= bpos;
 		const unsigned long long m = __ballot(node);
 		const uint32_t r = mtot + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-		S.rank_at[p] = (uint16_t)r;
-		if (node) S.npos[r] = (uint16_t)p;
+		rank_at[p] = (uint16_t)r;
+		if (node) npos[r] = (uint16_t)p;
 		mtot += (uint32_t)__popcll(m);
 		if (M512) {
 			const unsigned long long em = __ballot((by[sg] & 0x7fu) == 127u);
@@ -791,7 +796,7 @@ __device__ __forceinline__ uint32_t parse_chunk_nodes(ParseLds<NLV>& S, uint16_t
 	// ---- one lane per node: where its block ends, and the node that follows
 	const bool more = cs + PC <= bpos;                         // the stream continues into the next chunk
 	for (uint32_t k = lane; k < mtot; k += 64) {
-		const uint32_t p = S.npos[k], byte = S.b[p];
+		const uint32_t p = npos[k], byte = S.b[p];
 		uint32_t e = p + 1u;
 		if (byte == FILL_FLAG) e += M512 ? 1u + ((S.b[p + 1] & 0x7fu) == 127u ? 1u : 0u) : 1u;
 		else if (byte == NORMAL_FLAG) {
@@ -811,14 +816,13 @@ __device__ __forceinline__ uint32_t parse_chunk_nodes(ParseLds<NLV>& S, uint16_t
 			n = 1;
 			if (e >= (uint32_t)PC) j = J_EXIT | (e - PC);
 			else {
-				const uint32_t nx = S.rank_at[e];                  // a non-flag entry slides to the next node (:236-243)
+				const uint32_t nx = rank_at[e];                    // a non-flag entry slides to the next node (:236-243)
 				j = nx < mtot ? nx : (more ? J_EXIT : J_END);
 			}
 		}
 		S.jl[0][k] = (uint16_t)j;
 		if (eo) eo[k] = (uint16_t)(e | n << 15);
 		if (n0) n0[k] = (uint16_t)n;
-		if (mark) mark[k] = 0;
 	}
 	wave_lds_sync();
 	return mtot;
@@ -842,11 +846,13 @@ __global__ __launch_bounds__(64) void k_parse_chunks(ParseArgs A)
 #pragma unroll
 		for (int q = 0; q < PCD; q++) raw[q] = nxt[q];
 		if (c + gridDim.x < nch) load_chunk(nxt, fbits, (uint32_t)A.stride, (c + gridDim.x) * PC, lane);   // in flight over this chunk
-		const uint32_t mtot = parse_chunk_nodes<M512>(S, nullptr, nn[0], nullptr, raw, bpos, cs, lane);
-		// ---- PEL rounds of pointer doubling over the node list (jump + blocks counted along it), then the 33 entry
-		// lanes walk their chains 2^PEL nodes at a time
+		const uint32_t mtot = parse_chunk_nodes<M512>(S, /*rank_at*/ nn[1], /*npos*/ S.jl[1], nullptr, nn[0], raw, bpos, cs, lane);
+		const uint32_t k0 = lane < 33 ? nn[1][lane] : 0u;         // first node at or after entry offset `lane` (rank_at dies below)
+		wave_lds_sync();
+		// ---- PCL rounds of pointer doubling over the node list (jump + blocks counted along it), then the 33 entry
+		// lanes walk their chains 2^PCL nodes at a time
 #pragma unroll
-		for (int lv = 0; lv < PEL; lv++) {
+		for (int lv = 0; lv < PCL; lv++) {
 			const uint16_t *js = S.jl[lv & 1], *ns = nn[lv & 1];
 			uint16_t *jd = S.jl[(lv + 1) & 1], *nd = nn[(lv + 1) & 1];
 			for (uint32_t k = lane; k < mtot; k += 64) {
@@ -860,10 +866,10 @@ __global__ __launch_bounds__(64) void k_parse_chunks(ParseArgs A)
 		if (lane < 33) {
 			uint32_t ex = X_END, cnt = 0;
 			if (cs + lane <= bpos) {
-				uint32_t k = S.rank_at[lane];
+				uint32_t k = k0;
 				if (k >= mtot) { if (cs + PC <= bpos) ex = 0; }
 				else {
-					const uint16_t *jf = S.jl[PEL & 1], *nf = nn[PEL & 1];
+					const uint16_t *jf = S.jl[PCL & 1], *nf = nn[PCL & 1];
 					do { cnt += nf[k]; k = jf[k]; } while (k < J_EXIT);
 					if (k != J_END) ex = k & 0x3Fu;
 				}
@@ -916,7 +922,8 @@ __global__ __launch_bounds__(64) void k_parse_emit(ParseArgs A)
 {
 	__shared__ ParseLds<PEL + 1> S;
 	__shared__ uint16_t eo[PC];                                // node -> end of its block (chunk-relative, <= PC+32) | counts << 15
-	__shared__ uint8_t mark[PC];
+	uint8_t* mark = S.b;                                       // chain marks: in the staged bytes' space once the nodes are built
+	static_assert(PEL >= 2 && PC + PHALO >= PC, "rank_at / npos borrow jl[PEL-1] / jl[PEL], the marks borrow the bytes");
 	const int lane = threadIdx.x;
 	for (uint32_t f = blockIdx.y; f < A.n_frames; f += gridDim.y) {
 	const uint32_t g0 = A.cum[f], nch = A.cum[f + 1] - g0, bpos = A.bpos[f];
@@ -937,8 +944,10 @@ __global__ __launch_bounds__(64) void k_parse_emit(ParseArgs A)
 		if (o == 0xFFu) continue;                              // the chain ended before this chunk (uniform)
 		if (kb + 1u >= A.nblk) continue;                       // every block this chunk could enter is beyond the frame
 		const uint32_t cs = c * PC;
-		const uint32_t mtot = parse_chunk_nodes<M512>(S, eo, nullptr, mark, raw, bpos, cs, lane);
-		const uint32_t k0 = cs + o <= bpos ? S.rank_at[o] : mtot;
+		const uint32_t mtot = parse_chunk_nodes<M512>(S, /*rank_at*/ S.jl[PEL - 1], /*npos*/ S.jl[PEL], eo, nullptr, raw, bpos, cs, lane);
+		const uint32_t k0 = cs + o <= bpos ? S.jl[PEL - 1][o] : mtot;
+		for (uint32_t k = lane; k < mtot; k += 64) mark[k] = 0;
+		wave_lds_sync();
 		if (k0 < mtot) {
 			// PEL rounds of pointer doubling, then one lane walks the true chain 2^PEL nodes at a time and the kept
 			// levels fill in the nodes between (every node 2^lv steps behind a marked one)
