@@ -49,7 +49,13 @@ extern "C" const char* agmv_hip_last_error(void) { return g_err; }
 // ----------------------------------------------------------------------------------------------
 // geometry constants
 // ----------------------------------------------------------------------------------------------
-constexpr int ENC_T = 512;          // threads per encode workgroup = 4x4 blocks per tile
+#ifndef ENC_T_OVERRIDE
+#define ENC_T_OVERRIDE 512
+#endif
+#ifndef ENC_WPE
+#define ENC_WPE 4
+#endif
+constexpr int ENC_T = ENC_T_OVERRIDE;          // threads per encode workgroup = 4x4 blocks per tile
 constexpr int ENC_WAVES = ENC_T / 64;
 constexpr int MROW = 17;            // dwords per matrix row: 16 used + 1 pad (LDS bank spread)
 constexpr int DEC_T = 256;          // threads per decode workgroup
@@ -322,13 +328,15 @@ __device__ __forceinline__ void wave_copy_out(const uint8_t* stage, uint8_t* gds
 //                 (L) wave 0 resolves the decoupled look-back of frame f-1 (its status window was prefetched
 //                     before the compute); barrier; every wave copies its slice of stage[(f-1)&1] out.
 template <bool M512>
-__global__ __launch_bounds__(ENC_T, 4) void k_encode(EncArgs A)
+__global__ __launch_bounds__(ENC_T, ENC_WPE) void k_encode(EncArgs A)
 {
 	constexpr int NROWS = M512 ? 512 : 256;
 	extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
 	uint32_t* s_mtx = (uint32_t*)smem;                         // NROWS * MROW dwords
 	uint8_t* s_stage0 = smem + NROWS * MROW * 4;               // two stage buffers
-	uint32_t* s_misc = (uint32_t*)(s_stage0 + 2 * STAGE_SZ);   // [0..15] wave sums x2, [16..17] base x2, [18] ticket
+	uint32_t* s_misc = (uint32_t*)(s_stage0 + 2 * STAGE_SZ);   // wave sums x2, then base x2, then the ticket
+	constexpr int MISC_BASE = 2 * ENC_WAVES, MISC_TICKET = MISC_BASE + 2;
+	static_assert(MISC_TICKET < 32, "s_misc has 32 dwords");
 
 	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 	const uint32_t npx = A.w * A.h;
@@ -339,9 +347,9 @@ __global__ __launch_bounds__(ENC_T, 4) void k_encode(EncArgs A)
 
 	for (;;) {
 		__syncthreads();                                       // matrix ready / previous tile fully drained
-		if (tid == 0) s_misc[18] = atomicAdd(A.ctrl, 1u);
+		if (tid == 0) s_misc[MISC_TICKET] = atomicAdd(A.ctrl, 1u);
 		__syncthreads();
-		const uint32_t t = s_misc[18];
+		const uint32_t t = s_misc[MISC_TICKET];
 		if (t >= A.total_tiles) break;
 		// tile-major ticket order: consecutive tickets are the SAME tile of different GOPs, so a tile's
 		// predecessors (same GOP, lower tile) are n_groups tickets older -> mostly finished and already
@@ -510,7 +518,7 @@ __global__ __launch_bounds__(ENC_T, 4) void k_encode(EncArgs A)
 				}
 
 				// ---- byte offsets inside the tile: wave scan -> workgroup scan
-				uint32_t* wsum = s_misc + (f & 1) * 8;
+				uint32_t* wsum = s_misc + (f & 1) * ENC_WAVES;
 				const uint32_t incl = wave_incl_scan(len, lane);
 				if (lane == 63) wsum[wave] = incl;
 				lds_barrier();                                     // (A) every wave is done with its scratch slice
@@ -584,7 +592,7 @@ __global__ __launch_bounds__(ENC_T, 4) void k_encode(EncArgs A)
 						                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 				}
 				if (lane == 0) {
-					s_misc[16 + ((f - 1) & 1)] = excl;
+					s_misc[MISC_BASE + ((f - 1) & 1)] = excl;
 					if (tile == A.tpf - 1) A.sizes[f - 1] = excl + total_prev;   // usize of the frame
 				}
 			}
@@ -594,7 +602,7 @@ __global__ __launch_bounds__(ENC_T, 4) void k_encode(EncArgs A)
 #else
 			if (have_prev) {
 #endif
-				const uint32_t base = s_misc[16 + ((f - 1) & 1)];
+				const uint32_t base = s_misc[MISC_BASE + ((f - 1) & 1)];
 #ifdef ABL_NOCOPYOUT
 				if (base == 0xFFFFFFF0u)
 #endif
