@@ -1292,6 +1292,8 @@ __global__ __launch_bounds__(DEC_T, DEC_WPE) void k_decode(DecArgs A)
 		const int f = f_lo + i;
 		bool fill_written = false;
 		const bool entered = valid && blk < ne[i];
+		const uint32_t own3 = cur[3];                          // the block's pixel (3,0) and staleness before this frame
+		const bool stale0 = stale;
 		if (entered) {
 			StagedSrc src{(const __attribute__((address_space(3))) uint8_t*)s_bytes[i], r_lo[i], r_len[i], A.bits + (size_t)f * A.stride, (uint32_t)A.stride};
 			decode_block_staged<M512>(src, off[i], bp[i], s_pal, cur, icol, istale, stale, fill_written);
@@ -1301,7 +1303,11 @@ __global__ __launch_bounds__(DEC_T, DEC_WPE) void k_decode(DecArgs A)
 			s_nbstale[tid] = stale ? 1u : 0u;
 			lds_barrier();
 			if (is_last && fill_written) {
-				if (tid > 0) {
+				if (A.bw == 1) {                                   // one block per row: the reference's 64-bit (x-1) wraps to the
+#pragma unroll                                                     // block's own pixel (3,0), not yet written in this frame
+					for (int k = 0; k < 16; k++) cur[k] = own3;
+					stale = stale0;
+				} else if (tid > 0) {
 					uint32_t c = s_nb[tid - 1];
 #pragma unroll
 					for (int k = 0; k < 16; k++) cur[k] = c;
@@ -1394,15 +1400,17 @@ __global__ __launch_bounds__(64) void k_fixup(DecArgs A)
 		}
 		for (uint32_t f = 0; f < A.n_frames; f++) {
 			bool stale = false, fill_written = false;
+			const uint32_t own3 = cur[3];
 			if (active && blk < A.nentered[f]) {
 				ByteSrc src{A.bits + (size_t)f * A.stride, (uint32_t)A.stride};
 				decode_block<M512>(src, A.offsets[(size_t)f * A.nblk + blk], A.bpos[f], s_pal, cur, icol,
 				                   false, stale, fill_written);
 			}
 			uint32_t left = __shfl_up(cur[7], 1, 64);          // neighbour sits in lane-1 by construction
-			if (is_last && fill_written && lane > 0) {
+			if (is_last && fill_written && (lane > 0 || A.bw == 1)) {
+				const uint32_t c = A.bw == 1 ? own3 : left;        // one block per row: see k_decode
 #pragma unroll
-				for (int k = 0; k < 16; k++) cur[k] = left;
+				for (int k = 0; k < 16; k++) cur[k] = c;
 			}
 			if (((A.first_fc + f) & 3u) == 0) {
 #pragma unroll

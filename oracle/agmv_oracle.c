@@ -394,7 +394,9 @@ static int parse_block(orc_decoder* d, int mode512, uint32_t x, uint32_t y, uint
 		} else {
 			color = d->p0[index];
 		}
-		if (x == w - 4 && y == h - 4) color = d->img[(x - 1) + (size_t)(y + 1) * w];  /* :264-266 */
+		/* :264-266.  x, y are 64-bit `unsigned long` in the reference: for a frame one block wide (x == 0) the index
+		   wraps to (y+1)*w - 1, the block's own pixel (3,0) as it was before this frame */
+		if (x == w - 4 && y == h - 4) color = d->img[(size_t)x - 1 + (size_t)(y + 1) * w];
 		if (bitpos > bpos) { escape = 1; }
 		else
 			for (uint32_t j = 0; j < 4; j++)

@@ -287,6 +287,87 @@ def test_decode_truncated_and_garbage_streams(torch, hip):
             assert (got[t] == exp[t]).all(), "mode512=%s frame %d" % (mode512, t)
 
 
+@pytest.mark.parametrize("seed", range(int(os.environ.get("AGMV_FUZZ_SEEDS", "10"))))
+def test_fuzz_encode_decode_vs_oracle(torch, hip, seed):
+    """seeded fuzz: random geometry, frame count, colour mode and content mix, encode against the oracle encoder; then
+    the streams -- a third of them damaged (cut, bytes flipped to flag values, garbage spliced in) -- through the GPU
+    parser + reconstruct against the oracle decoder (resync, escape, stale tails, fix-up, last-block quirk)."""
+    rng = np.random.default_rng(1000 + seed)
+    W, H = 4 * int(rng.integers(1, 90)), 4 * int(rng.integers(1, 40))
+    n = int(rng.integers(1, 14))
+    mode512 = bool(rng.integers(0, 2))
+    frames, prevf = [], None
+    for t in range(n):
+        kind = int(rng.integers(0, 6))
+        if kind == 0 or prevf is None and kind == 3:
+            f = rng.integers(0, 1 << 24, size=(H, W), dtype=np.uint32)
+        elif kind == 1:
+            f = np.full((H, W), int(rng.integers(0, 1 << 24)), np.uint32)
+        elif kind == 2:
+            f = S.synth_frame(max(W, 8), max(H, 8), int(rng.integers(0, 50)))[:H, :W].copy()
+        elif kind == 3:
+            f = prevf.copy()
+        elif kind == 4:
+            f = (prevf if prevf is not None else np.zeros((H, W), np.uint32)) ^ rng.integers(0, 4, size=(H, W), dtype=np.uint32) * np.uint32(0x010101)
+        else:
+            f = np.repeat(np.repeat(rng.integers(0, 1 << 24, size=((H + 7) // 8, (W + 7) // 8), dtype=np.uint32), 8, 0), 8, 1)[:H, :W].copy()
+        frames.append(f.astype(np.uint32))
+        prevf = frames[-1]
+    frames = np.stack(frames)
+    p0, p1 = S.content_palettes(frames[:4]) if rng.integers(0, 2) else S.random_palettes(int(rng.integers(0, 1 << 30)))
+    hip.set_palette(p0, p1, mode512)
+    outs = gpu_encode(torch, hip, frames)
+    enc = O.OracleEncoder(W, H, mode512, p0, p1)
+    for t, f in enumerate(frames):
+        exp = enc.encode(f)
+        assert len(outs[t]) == len(exp) and (outs[t] == exp).all(), "encode frame %d first diff %s" % (t, first_diff(outs[t], exp))
+    bits = []
+    for b in outs:
+        b = b.copy()
+        hurt = int(rng.integers(0, 9))
+        if hurt == 0 and len(b) > 2:
+            b = b[:int(rng.integers(1, len(b)))]
+        elif hurt == 1:
+            for _ in range(int(rng.integers(1, 6))):
+                b[int(rng.integers(0, len(b)))] = [0x4E, 0x2F, 0x5E, 0x7F, 0xFF][int(rng.integers(0, 5))]
+        elif hurt == 2:
+            room = W * H * 3 + 64 - 16 - len(b)                # the oracle decoder's persistent buffer (w*h*3+64 bytes)
+            if room >= 1:
+                at = int(rng.integers(0, len(b)))
+                b = np.concatenate([b[:at], rng.integers(0, 256, int(rng.integers(1, min(70, room) + 1)), dtype=np.uint8), b[at:]])
+        bits.append(b)
+    dec = O.OracleDecoder(W, H, mode512, p0, p1)
+    exp, pads = [], []
+    for b in bits:
+        pix, padded, offs, n_ent = dec.decode(b, want_tables=True)
+        exp.append(pix)
+        pads.append(padded[len(b):len(b) + 16])
+    got, _, _ = gpu_decode(torch, hip, bits, pads, W, H)
+    for t in range(n):
+        assert (got[t] == exp[t]).all(), "decode frame %d of %d (%dx%d, mode512=%s)" % (t, n, W, H, mode512)
+
+
+@pytest.mark.parametrize("mode512", [True, False])
+@pytest.mark.parametrize("shape", [(4, 4), (4, 24), (4, 1028), (8, 8)])
+def test_decode_narrow_frames_vs_oracle(torch, hip, mode512, shape):
+    """one block per row (w == 4): the last-block FILL quirk falls on the block's OWN pixel (3,0) of the previous frame
+    (the reference's 64-bit x-1 wraps); pinned against the compiled reference in tests/test_oracle.py."""
+    W, H = shape
+    rng = np.random.default_rng(W * 7 + H)
+    frames = [np.full((H, W), int(c), np.uint32) for c in rng.integers(0, 1 << 24, 5)]
+    noise = rng.integers(0, 1 << 24, size=(H, W), dtype=np.uint32)
+    frames += [noise, frames[1].copy(), frames[2].copy(), noise ^ np.uint32(1)]
+    frames = np.stack(frames)
+    p0, p1 = S.content_palettes(frames[:4])
+    hip.set_palette(p0, p1, mode512)
+    outs = gpu_encode(torch, hip, frames)
+    dec = O.OracleDecoder(W, H, mode512, p0, p1)
+    exp = [dec.decode(b) for b in outs]
+    got, _, _ = gpu_decode(torch, hip, outs, None, W, H)
+    for t in range(len(frames)):
+        assert (got[t] == exp[t]).all(), "frame %d" % t
+
+
 def test_parallel_parser_matches_serial_walk(torch, hip, monkeypatch):
     """the chunked pointer-doubling parser (k_parse_chunks/stitch/emit) against the one-lane-per-frame
     walk (k_parse_serial) on streams the CPU oracle is too slow for: 1080p clips (COPY-heavy P-frames =

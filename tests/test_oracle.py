@@ -156,3 +156,31 @@ def test_interp_vs_ref():
     O.oracle().orc_interp_frame(x, a, b, len(a))
     O.ref().refshim_interp(y, a, b, 64, 64)
     assert (x == y).all()
+
+
+@needs_ref
+@pytest.mark.parametrize("mode512", [True, False])
+@pytest.mark.parametrize("shape", [(4, 4), (4, 24), (8, 8)])
+def test_decode_narrow_frames_vs_ref(tmp_path, mode512, shape):
+    """frames one block wide: the reference's last-block FILL quirk reads img_data[(x-1)+(y+1)*w] with 64-bit unsigned
+    x == 0, which wraps to the block's own pixel (3,0) (src/agmv_decode.c:264-266).  File written by the reference's
+    per-frame encoder, decoded by the reference and by the restatement."""
+    W, H = shape
+    rng = np.random.default_rng(W * 100 + H)
+    frames = [np.full((H, W), int(c), np.uint32) for c in rng.integers(0, 1 << 24, 5)]
+    frames += [rng.integers(0, 1 << 24, size=(H, W), dtype=np.uint32), frames[1].copy(), frames[2].copy()]
+    p0, p1 = S.content_palettes(frames[:4])
+    path = str(tmp_path / "narrow.agmv").encode()
+    a = O.ref().refshim_create(W, H, 3 if mode512 else 2, 1, p0, p1)
+    O.ref().refshim_write_header(a, path)
+    for f in frames:
+        O.ref().refshim_encode_frame_file(a, path, np.ascontiguousarray(f.reshape(-1)), 0)
+    O.ref().refshim_destroy(a)
+    data = bytearray(open(path, "rb").read())
+    data[4:8] = len(frames).to_bytes(4, "little")           # num_of_frames, patched by the sequence drivers only
+    open(path, "wb").write(data)
+    err, info, fr = O.oracle_decode_file(bytes(data), want_tables=True)
+    rerr, rinfo, rf = O.ref_decode_file(path.decode())
+    assert err == rerr == 0 and len(fr) == len(rf) == len(frames)
+    for t, (x, y) in enumerate(zip(fr, rf)):
+        assert (x["pix"] == y["pix"]).all(), "frame %d" % t
