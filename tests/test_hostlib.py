@@ -230,3 +230,39 @@ def test_display_frame_and_header_export(tmp_path):
     for (x, y) in ((-1, 0), (0, -1), (6, 0), (0, 4), (5, 3), (2, 1)):
         L.PlotPixel(vram.ctypes.data, x, y, 6, 4, 0xABCDEF)
     assert sorted(np.nonzero(vram)[0].tolist()) == [2 + 6, 5 + 18]
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("AGMV_FUZZ_SEEDS", "24"))))
+def test_lz_fuzz_vs_brute_force_oracle(seed):
+    """seeded fuzz of the fast LZSS / LZ77 against the brute-force restatement: bitstream-like inputs (flag bytes,
+    runs, repeated fragments at random distances, noise) of random length; also decode(fast encode) == input."""
+    rng = np.random.default_rng(9000 + seed)
+    n = int(rng.integers(1, 6000))
+    parts, have = [], 0
+    while have < n:
+        kind = int(rng.integers(0, 5))
+        ln = int(rng.integers(1, 400))
+        if kind == 0:
+            p = rng.integers(0, 256, ln, dtype=np.uint8)
+        elif kind == 1:
+            p = np.full(ln, [0x5E, 0x4E, 0x2F, 0, 0xFF][int(rng.integers(0, 5))], np.uint8)
+        elif kind == 2 and parts:
+            src = np.concatenate(parts)
+            at = int(rng.integers(0, len(src)))
+            p = src[at:at + ln].copy()
+        elif kind == 3:
+            p = np.tile(rng.integers(0, 256, int(rng.integers(1, 20)), dtype=np.uint8), ln // 4 + 1)[:ln]
+        else:
+            p = rng.integers(0, 4, ln, dtype=np.uint8) + np.uint8(0x4C)
+        parts.append(p)
+        have += len(p)
+    x = np.concatenate(parts)[:n]
+    L = O.oracle()
+    xin = np.concatenate([x, np.zeros(8, np.uint8)])
+    for name, fast, slow in (("lzss", H.lzss, L.orc_lzss_compress), ("lz77", H.lz77, L.orc_lz77_compress)):
+        out = np.zeros(4 * len(x) + 64, np.uint8)
+        cs = C.c_uint32()
+        slow(xin, len(x), out, C.byref(cs))
+        got, gcs = fast(x)
+        assert gcs == cs.value, (name, seed)
+        assert (got == out[:cs.value]).all(), (name, seed)
