@@ -345,6 +345,19 @@ def test_fuzz_encode_decode_vs_oracle(torch, hip, seed):
     got, _, _ = gpu_decode(torch, hip, bits, pads, W, H)
     for t in range(n):
         assert (got[t] == exp[t]).all(), "decode frame %d of %d (%dx%d, mode512=%s)" % (t, n, W, H, mode512)
+    # the same clip in random batches, state carried between calls like agmv->iframe_entries (encode) and
+    # frame->img_data / iframe->img_data (decode): batches that start inside a GOP, single-frame batches
+    cuts = sorted(set([0, n] + [int(c) for c in rng.integers(0, n + 1, int(rng.integers(0, 4)))]))
+    ient = torch.zeros(W * H, dtype=torch.int16, device="cuda")
+    for lo, hi in zip(cuts[:-1], cuts[1:]):
+        part = gpu_encode(torch, hip, frames[lo:hi], first_fc=lo, ientries=ient)
+        for t in range(lo, hi):
+            assert len(part[t - lo]) == len(outs[t]) and (part[t - lo] == outs[t]).all(), "batched encode frame %d (batch %d..%d)" % (t, lo, hi)
+        prev = exp[lo - 1].reshape(H, W) if lo else None
+        previ = exp[(lo - 1) // 4 * 4].reshape(H, W) if lo else None
+        gotb, _, _ = gpu_decode(torch, hip, bits[lo:hi], pads[lo:hi], W, H, first_fc=lo, prev=prev, prev_iframe=previ)
+        for t in range(lo, hi):
+            assert (gotb[t - lo] == exp[t]).all(), "batched decode frame %d (batch %d..%d)" % (t, lo, hi)
 
 
 @pytest.mark.parametrize("mode512", [True, False])
@@ -400,6 +413,55 @@ def test_parallel_parser_matches_serial_walk(torch, hip, monkeypatch):
         for f in range(n):
             assert torch.equal(o_ser[f, :ne[f]], o_par[f, :ne[f]]), "mode512=%s frame %d (nentered %d of %d)" % (mode512, f, ne[f], nblk)
         monkeypatch.delenv("AGMV_HIP_PARSE", raising=False)
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("AGMV_FUZZ_SEEDS", "6"))))
+def test_fuzz_parser_random_bytes(torch, hip, monkeypatch, seed):
+    """parallel parser against the one-lane serial walk on BYTE SOUP: every stream is random bytes drawn from a
+    distribution rich in flag values, escape codes and near-misses, with random lengths (chunk boundaries, empty,
+    one byte) and random stale tails -- the map/stitch/emit logic with no help from well-formed structure."""
+    rng = np.random.default_rng(5000 + seed)
+    W, H = 4 * int(rng.integers(1, 200)), 4 * int(rng.integers(1, 120))
+    n = int(rng.integers(1, 9))
+    mode512 = bool(rng.integers(0, 2))
+    stride = int(rng.choice([256, 512, 768, 1024, 4096, 20480, 66048]))
+    alphabet = np.array([0x4E, 0x2F, 0x5E, 0x7F, 0xFF, 0x4F, 0x2E, 0x5F, 0x00, 0x80] + list(rng.integers(0, 256, 6)), np.uint8)
+    probs = rng.dirichlet(np.ones(len(alphabet)) * float(rng.choice([0.3, 1.0, 5.0])))
+    bits = rng.choice(alphabet, size=(n, stride), p=probs).astype(np.uint8)
+    mix = rng.random((n, stride)) < float(rng.choice([0.0, 0.1, 0.5]))
+    bits[mix] = rng.integers(0, 256, int(mix.sum()), dtype=np.uint8)
+    bpos = np.array([int(rng.choice([0, 1, 2, 511, 512, 513, 1023, 1024, stride - 16, int(rng.integers(0, stride - 15))])) for _ in range(n)], np.int32)
+    bpos = np.clip(bpos, 0, stride - 16)
+    p0, p1 = S.random_palettes(seed)
+    hip.set_palette(p0, p1, mode512)
+    exp = None
+    if W * H <= 40000:                                        # small enough for the CPU oracle: pixels must match it too
+        bpos = np.minimum(bpos, W * H * 3 + 64 - 16).astype(np.int32)       # its persistent buffer
+        dec, exp = O.OracleDecoder(W, H, mode512, p0, p1), []
+        for f in range(n):
+            pix, padded, _, _ = dec.decode(bits[f, :bpos[f]], want_tables=True)
+            bits[f, bpos[f]:bpos[f] + 16] = padded[bpos[f]:bpos[f] + 16]    # what the reference's buffer holds there
+            exp.append(pix)
+    dbits, dbpos = torch.from_numpy(bits).cuda(), torch.from_numpy(bpos).cuda()
+    monkeypatch.setenv("AGMV_HIP_PARSE", "serial")
+    o_ser, n_ser = hip.parse_dev(dbits, dbpos, n, W, H)
+    torch.cuda.synchronize()
+    monkeypatch.delenv("AGMV_HIP_PARSE")
+    o_par, n_par = hip.parse_dev(dbits, dbpos, n, W, H)
+    torch.cuda.synchronize()
+    ne = n_ser.cpu().numpy()
+    assert torch.equal(n_ser, n_par), (ne, n_par.cpu().numpy(), bpos)
+    for f in range(n):
+        assert torch.equal(o_ser[f, :ne[f]], o_par[f, :ne[f]]), "frame %d bpos %d nentered %d (%dx%d mode512=%s stride %d)" % (f, bpos[f], ne[f], W, H, mode512, stride)
+    # and the reconstruct step must agree with itself on both tables (fix-up path: almost every block is stale here)
+    a = hip.decode_dev(dbits, dbpos, o_ser, n_ser, n, W, H, 0)
+    b = hip.decode_dev(dbits, dbpos, o_par, n_par, n, W, H, 0)
+    torch.cuda.synchronize()
+    assert torch.equal(a, b)
+    if exp is not None:
+        got = to_u32(b).reshape(n, -1)
+        for f in range(n):
+            assert (got[f] == exp[f]).all(), "pixels frame %d bpos %d (%dx%d mode512=%s)" % (f, bpos[f], W, H, mode512)
 
 
 # ------------------------------------------------------------------------------- helpers
