@@ -58,7 +58,10 @@ extern "C" const char* agmv_hip_last_error(void) { return g_err; }
 constexpr int ENC_T = ENC_T_OVERRIDE;          // threads per encode workgroup = 4x4 blocks per tile
 constexpr int ENC_WAVES = ENC_T / 64;
 constexpr int MROW = 17;            // dwords per matrix row: 16 used + 1 pad (LDS bank spread)
-constexpr int DEC_T = 256;          // threads per decode workgroup
+#ifndef DEC_T_OVERRIDE
+#define DEC_T_OVERRIDE 256
+#endif
+constexpr int DEC_T = DEC_T_OVERRIDE;          // threads per decode workgroup
 #ifndef DEC_BPB
 #define DEC_BPB 24
 #endif
@@ -703,7 +706,6 @@ __global__ __launch_bounds__(64) void k_parse_serial(const uint8_t* __restrict__
 // ----------------------------------------------------------------------------------------------
 constexpr int PC = 512;         // bytes per chunk (one wave)
 constexpr int PNSEG = PC / 64;  // ballot segments per chunk
-constexpr int PLV = 9;          // doubling levels: 2^9 >= nodes in a chunk
 #ifndef PEL_OVERRIDE
 #define PEL_OVERRIDE 3
 #endif
