@@ -55,6 +55,21 @@ extern "C" const char* agmv_hip_last_error(void) { return g_err; }
 #ifndef ENC_WPE
 #define ENC_WPE 4
 #endif
+#ifndef ENC_DF
+#define ENC_DF 0
+#endif
+#ifndef ENC_XCD
+#define ENC_XCD 0
+#endif
+#ifndef ENC_BAND
+#define ENC_BAND 4
+#endif
+#ifndef ENC_PIXAUX
+#define ENC_PIXAUX 0
+#endif
+#ifndef ENC_PKEMIT
+#define ENC_PKEMIT 0
+#endif
 constexpr int ENC_T = ENC_T_OVERRIDE;          // threads per encode workgroup = 4x4 blocks per tile
 constexpr int ENC_WAVES = ENC_T / 64;
 constexpr int MROW = 17;            // dwords per matrix row: 16 used + 1 pad (LDS bank spread)
@@ -67,7 +82,11 @@ constexpr int DEC_T = DEC_T_OVERRIDE;          // threads per decode workgroup
 #endif
 constexpr int DEC_STAGE = DEC_T * DEC_BPB;   // LDS window for a tile's bitstream bytes in ONE frame (24 B per block; beyond it bytes come from global memory); x4 frames = 24 KB, 5 workgroups per CU
 constexpr int DEC_SR = DEC_STAGE / 4 / DEC_T;   // dwords of the window each lane carries from global memory to LDS
-constexpr uint32_t LUT_ENTRIES = 1u << 24;
+#ifndef LUT_SPARSE
+#define LUT_SPARSE 0
+#endif
+constexpr uint32_t LUT_COLOURS = 1u << 24;
+constexpr uint32_t LUT_ENTRIES = LUT_SPARSE ? (1u << 28) : (1u << 24);   // index space of the table (see lut_index)
 
 constexpr unsigned long long ST_AGG = 1ull << 32;     // look-back status tags (high word)
 constexpr unsigned long long ST_PREFIX = 2ull << 32;
@@ -106,8 +125,14 @@ extern "C" size_t agmv_hip_max_usize(uint32_t w, uint32_t h, int mode512)
 // R,G,B table).  index = R[7:2] G[7:2] B[7:2] | R[1:0] G[1:0] B[1:0]
 __host__ __device__ __forceinline__ uint32_t lut_index(uint32_t px)
 {
+#if LUT_SPARSE
+	// same 4x4x4 cubes, but the cube number keeps the 2-bit holes of the masked pixel (R6 .. G6 .. B6): 6 VALU per
+	// look-up instead of 12; the table spans 512 MiB of address space, 32 MiB of it populated (8 KiB runs every 32 KiB)
+	return ((px & 0xFCFCFCu) << 4) | ((((px & 0x030303u) * 0x10410u) >> 16) & 0x3Fu);
+#else
 	return (px & 0xFC0000u) | ((px & 0xFC00u) << 2) | ((px & 0xFCu) << 4) | (px & 3u) | ((px >> 6) & 0xCu) |
 	       ((px >> 12) & 0x30u);
+#endif
 }
 
 // ----------------------------------------------------------------------------------------------
@@ -188,7 +213,7 @@ struct EncArgs {
 	uint32_t* ctrl;
 	uint16_t* ientries;
 	unsigned long long out_stride;
-	uint32_t n_frames, w, h, bw, nblk, tpf, first_fc, phase, n_groups, last_iframe, total_tiles;
+	uint32_t n_frames, w, h, bw, nblk, tpf, first_fc, phase, n_groups, last_iframe, total_tiles, n_xcd;
 };
 
 // Workgroup barrier that orders LDS only.  __syncthreads() also carries a global-memory fence, i.e. an
@@ -289,7 +314,7 @@ constexpr int WSLICE = WBLK * 33;                              // stage bytes a 
 constexpr int STAGE_SZ = 4 + ENC_T * 33 + 12;                  // front pad + worst case + tail pad
 static_assert(STAGE_SZ % 16 == 0 && WSLICE % 16 == 0, "stage buffers / slices must stay 16-byte aligned");
 static_assert(WSLICE >= WBLK * 16 * 2 + 16, "the entry transpose scratch aliases the wave's stage slice");
-constexpr size_t CTRL_BYTES = 16;                              // [0] ticket, [1] error
+constexpr size_t CTRL_BYTES = 256;                             // [0] ticket, [1] error, [16..31] per-XCD tickets
 
 // copy staged bytes [lo, hi) of a tile to the frame bitstream (gdst = address of staged byte 0), one wave:
 // dword stores on global-aligned dwords (staged byte i lives at stage byte 4+i), bytes at the ragged ends.
@@ -321,6 +346,7 @@ __device__ __forceinline__ void wave_copy_out(const uint8_t* stage, uint8_t* gds
 	}
 }
 
+#if !ENC_DF
 // K1.  One workgroup = one tile of 512 consecutive 4x4 blocks (8 waves x 64 blocks), carried through the
 // <=4 frames of one GOP; one lane owns one block for classification/emission.  Software-pipelined by one frame:
 //   iteration f:  (Q) quantise with lane = (block, row): wide row loads, each LUT gather instruction covers a
@@ -619,6 +645,523 @@ __global__ __launch_bounds__(ENC_T, ENC_WPE) void k_encode(EncArgs A)
 		}
 	}
 }
+
+#else
+// K1 (barrier-free form).  One workgroup = one tile of ENC_T consecutive 4x4 blocks (ENC_WAVES waves x 64 blocks), one
+// lane = one block for classification/emission, carried through the <=4 frames of its GOP.  The stream of
+// (tile, frame) items a workgroup processes is ONE software pipeline that runs across tile switches; the waves of a
+// workgroup never meet at a barrier inside it -- they exchange single tagged LDS words:
+//   item `it`, every wave:  (Q) quantise with lane = (block, row): wide row loads, each LUT gather instruction covers a
+//                               64x4-pixel patch; entries transposed to lane = block through the wave's own stage slot
+//                           prefetch of the next item's pixels (next frame, or the first frame of the NEXT tile, whose
+//                               ticket was drawn one tile earlier)
+//                           (C) classify FILL / COPY / NORMAL, wave scan of the byte lengths -> wsum[it][wave];
+//                               the LAST wave to arrive (LDS counter) adds the tile up and publishes the aggregate
+//                           (E) emit bytes into the wave's OWN stage slot (offsets inside the wave only)
+//                           copy-out of item it-1 from its own slot, at gbase[it-1][wave]
+//   item `it`, duty wave (rotating): decoupled look-back of item it-1 across tiles (status window prefetched ahead
+//                               of the look-ups), then gbase[it-1][w] = tile offset + bytes of the lower waves.
+// Waves therefore drift apart by up to ~1.5 items, and the phases (look-up issue, look-up wait, LDS, VALU) of the
+// waves sharing a SIMD interleave instead of lining up behind a barrier.  Control words live in 4 slots (it & 3): a
+// wave can finish item `it` only after gbase[it-1] exists, i.e. after EVERY wave has published wsum[it-1]; so when a
+// slot is rewritten for item it+1 all waves have finished item it-2 and with it every read of item it-3's words.
+constexpr int DF_SLOTS = 8;
+constexpr int WSLOT = 16 + WBLK * 33 + 16;                     // a wave's stage slot: front pad + worst case + tail pad
+static_assert(WSLOT % 16 == 0 && WSLOT >= 16 + WBLK * 16 * 2, "slot alignment / transpose scratch");
+constexpr int C_WSUM = 0;                                      // [slot][wave]      tag<<16 | bytes of the wave
+constexpr int C_ARRIVE = C_WSUM + DF_SLOTS * ENC_WAVES;        // [slot]            waves that have published wsum
+constexpr int C_TTOTAL = C_ARRIVE + DF_SLOTS;                  // [slot]            tag<<16 | bytes of the tile
+constexpr int C_GBASE = C_TTOTAL + DF_SLOTS;                   // [slot][wave][2]   frame byte offset of the wave, tag
+constexpr int C_TICKET = C_GBASE + DF_SLOTS * ENC_WAVES * 2;   // [slot][2]         ticket of tile sequence number s, s
+constexpr int C_END = C_TICKET + DF_SLOTS * 2;
+constexpr size_t ENC_LDS_EXTRA = 2 * ENC_WAVES * WSLOT + C_END * 4;
+
+typedef uint16_t __attribute__((aligned(1))) u16u;          // byte-aligned 16/32-bit LDS stores (DS unaligned mode)
+typedef uint32_t __attribute__((aligned(1))) u32u;
+typedef uint16_t u16x2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) uint32_t lds_u32;   // explicit LDS pointers: ds_read / ds_write, never flat
+__device__ __forceinline__ uint32_t lds_ld(const uint32_t* p) { return *(const volatile lds_u32*)p; }
+__device__ __forceinline__ void lds_st(uint32_t* p, uint32_t v) { *(volatile lds_u32*)p = v; }
+
+// wave-uniform bounded spin until the word at p satisfies (v >> shift) == tag; returns the word
+__device__ __forceinline__ uint32_t lds_wait(const uint32_t* p, uint32_t tag, int shift, uint32_t* ctrl, int lane)
+{
+	uint32_t v = __builtin_amdgcn_readfirstlane(lds_ld(p));
+	unsigned spins = 0;
+	while ((v >> shift) != tag) {
+		__builtin_amdgcn_s_sleep(1);
+		if (++spins > (1u << 18)) {
+			if (lane == 0) atomicExch(ctrl + 1, 2u);
+			break;
+		}
+		v = __builtin_amdgcn_readfirstlane(lds_ld(p));
+	}
+	return v;
+}
+
+// copy the `total` bytes staged at slot+16 to gdst (one wave): dword stores on GLOBAL-aligned dwords, byte stores at
+// the two ragged ends (which share a dword with the neighbouring waves / tiles)
+__device__ __forceinline__ void wave_copy_own(const uint8_t* slot, uint8_t* gdst, uint32_t total, int lane)
+{
+	const uint32_t s = (uint32_t)((uintptr_t)gdst & 3u);
+	uint8_t* g0 = gdst - s;
+	const uint32_t nd = (s + total + 3u) >> 2;
+	const uint32_t* s32 = (const uint32_t*)(slot + 12);       // s32[d+1] = staged bytes 4d .. 4d+3
+	for (uint32_t d = lane; d < nd; d += 64) {
+		const int t0 = (int)(4u * d) - (int)s;                 // staged byte held by the dword's first byte
+		if (t0 >= 0 && (uint32_t)t0 + 4u <= total) {
+			const uint32_t a = s32[d], b = s32[d + 1];
+			*(uint32_t*)(g0 + 4u * d) = s ? __builtin_amdgcn_alignbyte(b, a, 4u - s) : b;
+		} else {
+#pragma unroll
+			for (int q = 0; q < 4; q++) {
+				const int t = t0 + q;
+				if (t >= 0 && (uint32_t)t < total) g0[4u * d + q] = slot[16 + t];
+			}
+		}
+	}
+}
+
+// Tickets.  Flat form: one counter, tile-major over all GOPs (consecutive tickets = the same tile of different GOPs).
+// XCD form (ENC_XCD): every XCD has its own L2, and the table lines a tile needs follow its colours, so GOP g belongs
+// to XCD g % n_xcd and each XCD walks ITS GOPs in bands of ENC_BAND, tile-major inside a band: the workgroups that share
+// an L2 then work on a few neighbouring tiles of a few GOPs, whose table lines fit it, instead of on every GOP of the
+// clip at once.  A drained XCD steals from the next counter.  Either way a tile's predecessors (same GOP, lower tile)
+// carry older tickets of the same counter, so they are running or finished (forward progress of the look-back).
+// Returns tile * n_groups + group, or 0xffffffff when nothing is left.
+__device__ __forceinline__ uint32_t xcd_ticket_decode(const EncArgs& A, uint32_t k, uint32_t j)
+{
+	const uint32_t cnt = (A.n_groups - k + A.n_xcd - 1) / A.n_xcd;     // GOPs of XCD k (k < n_groups)
+	const uint32_t per_band = ENC_BAND * A.tpf;
+	const uint32_t b = j / per_band, r = j - b * per_band;
+	const uint32_t g0 = b * ENC_BAND, bsize = cnt - g0 < ENC_BAND ? cnt - g0 : ENC_BAND;
+	const uint32_t tile = r / bsize, lg = g0 + (r - tile * bsize);
+	return tile * A.n_groups + (k + lg * A.n_xcd);
+}
+
+__device__ __forceinline__ uint32_t draw_ticket(const EncArgs& A, uint32_t xcd, uint32_t first)
+{
+#if ENC_XCD
+	// `first` = ticket already drawn from the own counter
+	uint32_t k = xcd, j = first;
+	for (uint32_t tries = 0; tries < A.n_xcd; tries++) {
+		if (k < A.n_groups) {
+			const uint32_t cnt = (A.n_groups - k + A.n_xcd - 1) / A.n_xcd;
+			if (j < cnt * A.tpf) return xcd_ticket_decode(A, k, j);
+		}
+		k = k + 1 == A.n_xcd ? 0 : k + 1;
+		if (tries + 1 < A.n_xcd) j = atomicAdd(A.ctrl + 16 + k, 1u);
+	}
+	return 0xffffffffu;
+#else
+	return first;
+#endif
+}
+
+struct EncGeo {
+	uint32_t tile, wbase, wb_c, wbx, wby;                      // wave-uniform
+	int f_lo, f_hi, path;
+	uint32_t poff, p0b, qx0;                                   // per lane
+	bool valid;
+};
+
+template <bool M512>
+__global__ __launch_bounds__(ENC_T, ENC_WPE) void k_encode(EncArgs A)
+{
+	constexpr int NROWS = M512 ? 512 : 256;
+	extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+	uint32_t* s_mtx = (uint32_t*)smem;                         // NROWS * MROW dwords
+	uint8_t* s_stage0 = smem + NROWS * MROW * 4;               // [2][ENC_WAVES] stage slots
+	uint32_t* s_ctl = (uint32_t*)(s_stage0 + 2 * ENC_WAVES * WSLOT);
+
+	const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+	const uint32_t npx = A.w * A.h;
+	const uint32_t jb = lane >> 2, prow = lane & 3;            // quantise phase: lane = (block jb of 16, row prow)
+	const __amdgpu_buffer_rsrc_t lut_rs = __builtin_amdgcn_make_buffer_rsrc((void*)A.lut, 0, (int)(LUT_ENTRIES * 2u), 0x00020000);
+
+	for (int i = tid; i < NROWS * MROW; i += ENC_T) s_mtx[i] = A.mtx[i];
+	for (int i = tid; i < C_END; i += ENC_T) s_ctl[i] = 0;
+	__syncthreads();
+#if ENC_XCD
+	const uint32_t xcd = (__builtin_amdgcn_s_getreg((3 << 11) | 20) & 15u) % A.n_xcd;   // HW_REG_XCC_ID[3:0]
+	uint32_t* const my_ctr = A.ctrl + 16 + xcd;
+#else
+	const uint32_t xcd = 0;
+	uint32_t* const my_ctr = A.ctrl;
+#endif
+	if (tid == 0) s_ctl[C_TICKET] = draw_ticket(A, xcd, atomicAdd(my_ctr, 1u));
+	__syncthreads();                                           // the only workgroup barriers of the kernel
+
+	auto locate = [&](const EncGeo& g, uint32_t B, uint32_t& qx, uint32_t& qy) {   // block index (>= wb_c) -> block column / row
+		if (B >= A.nblk) B = A.nblk - 1;                       // blocks past the frame re-use the last valid one
+		qx = g.wbx + (B - g.wb_c); qy = g.wby;
+		while (qx >= A.bw) { qx -= A.bw; qy++; }
+	};
+	// tile-major ticket order: consecutive tickets are the SAME tile of different GOPs, so a tile's predecessors (same
+	// GOP, lower tile) are n_groups tickets older -> mostly finished when the look-back reads them.
+	// geometry: ONE integer division per wave (of its first block, wave-uniform); lane positions follow by adding and
+	// wrapping at the end of a block row (no per-lane divisions)
+	auto setup = [&](uint32_t t, EncGeo& g) {
+		g.tile = t / A.n_groups;
+		const uint32_t group = t - g.tile * A.n_groups;
+		g.f_lo = group == 0 ? 0 : (int)(group * 4 - A.phase);
+		g.f_hi = (int)(group * 4 - A.phase) + 4;
+		if (g.f_hi > (int)A.n_frames) g.f_hi = (int)A.n_frames;
+		g.wbase = g.tile * ENC_T + wave * WBLK;                // first block of this wave
+		g.wb_c = g.wbase < A.nblk ? g.wbase : A.nblk - 1;
+		g.wby = __builtin_amdgcn_readfirstlane(g.wb_c / A.bw); g.wbx = g.wb_c - g.wby * A.bw;
+		// lane-as-block view (classification, emission, I-frame entry plane)
+		const uint32_t blk = g.wbase + lane;
+		g.valid = blk < A.nblk;
+		uint32_t bx, by;
+		locate(g, blk, bx, by);
+		g.poff = by * 4 * A.w + bx * 4;                        // top-left pixel of the block
+		// quantise view, lane = (block, row): load i (0..3) fetches row `prow` (16 bytes) of block wbase + 16i + jb, so
+		// one instruction reads four 256-byte row segments of 16 adjacent blocks and each of its four pixel columns is
+		// a 64x4-pixel patch for the LUT gather.  A wave inside one block row uses immediate offsets, one crossing a
+		// single row boundary adds 3*w past it, anything else locates each of its four blocks.
+		uint32_t qy0;
+		locate(g, g.wbase + jb, g.qx0, qy0);
+		g.p0b = ((qy0 * 4 + prow) * A.w + g.qx0 * 4) * 4u;
+		g.path = (g.wbase + WBLK > A.nblk || g.wbx + WBLK > 2 * A.bw) ? 2 : (g.wbx + WBLK > A.bw ? 1 : 0);
+	};
+	auto load_frame = [&](const EncGeo& g, const uint32_t* fp, uint4 (&dst)[4]) {
+		const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)fp, 0, (int)(npx * 4u), 0x00020000);
+		const uint32_t w3b = 12u * A.w;
+		if (g.path == 0) {
+#pragma unroll
+			for (int i = 0; i < 4; i++) dst[i] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rs, g.p0b + 256 * i, 0, ENC_PIXAUX));
+		} else if (g.path == 1) {
+#pragma unroll
+			for (int i = 0; i < 4; i++)
+				dst[i] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rs, g.p0b + 256 * i + (g.qx0 + 16 * i >= A.bw ? w3b : 0u), 0, ENC_PIXAUX));
+		} else {
+#pragma unroll
+			for (int i = 0; i < 4; i++) {
+				uint32_t qx, qy;
+				locate(g, g.wbase + jb + 16 * i, qx, qy);
+				dst[i] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rs, ((qy * 4 + prow) * A.w + qx * 4) * 4u, 0, ENC_PIXAUX));
+			}
+		}
+	};
+
+	EncGeo g, gn;
+	uint32_t ticket = __builtin_amdgcn_readfirstlane(lds_ld(&s_ctl[C_TICKET]));
+	bool have = ticket < A.total_tiles;
+	if (have) setup(ticket, g);
+	uint32_t seq = 0, it = 0;                                  // tile sequence number, item number (tags / slots)
+	int f = have ? g.f_lo : 0;
+	bool new_tile = true;
+	uint32_t ip[8];                                            // the GOP's I-frame entries of this block, two u16 per register
+	uint4 px[4];
+	if (have) load_frame(g, A.pix + (size_t)f * npx, px);
+	bool have_prev = false, have_prev2 = false;                // items it-1 / it-2: tile, frame, bytes of this wave
+	uint32_t p_tile = 0, p_len = 0, p2_len = 0;
+	int p_f = 0, p2_f = 0;
+	uint32_t tk = 0;
+
+#ifdef ENC_PROF
+	uint32_t prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+	unsigned long long pt = __builtin_amdgcn_s_memtime();
+#define PSTAMP(k) do { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); prof[k] += (uint32_t)(n_ - pt); pt = n_; } while (0)
+#else
+#define PSTAMP(k) do { } while (0)
+#endif
+	for (;;) {
+		const uint32_t slot = it & (DF_SLOTS - 1), tag = (it + 1) & 0xffffu;
+		const uint32_t pslot = (it - 1) & (DF_SLOTS - 1), ptag = it & 0xffffu;
+		// (L) the look-back of item it-1 is the duty of ONE wave (rotating), done while its own table look-ups are in
+		// flight: the status window is loaded first, so it has landed when the look-ups have (in-order counter)
+		const bool duty = have_prev && wave == (int)(it % ENC_WAVES);
+		unsigned long long pre = ST_PREFIX;
+		if (duty && p_tile != 0) pre = st_load(A.status + (size_t)p_f * A.tpf, (int)p_tile - 1 - lane);
+		auto resolve_prev = [&]() {                            // tile offset of item it-1, usize of the frame, gbase[]
+			unsigned long long* st = A.status + (size_t)p_f * A.tpf;
+			uint32_t excl = 0;
+			if (p_tile != 0) excl = lookback(st, (int)p_tile, lane, A.ctrl, pre);
+			const uint32_t tot = lds_wait(&s_ctl[C_TTOTAL + pslot], ptag, 16, A.ctrl, lane) & 0xffffu;
+			if (lane == 0) {
+				if (p_tile != 0)
+					__hip_atomic_store(st + p_tile, ST_PREFIX | (unsigned long long)(excl + tot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				if (p_tile == A.tpf - 1) A.sizes[p_f] = excl + tot;   // usize of the frame
+			}
+			// every wave of the tile has published its byte count (the tile total exists): exclusive scan over the waves
+			const uint32_t ws = lane < ENC_WAVES ? (lds_ld(&s_ctl[C_WSUM + pslot * ENC_WAVES + lane]) & 0xffffu) : 0u;
+			uint32_t inc = ws;
+#pragma unroll
+			for (int d = 1; d < ENC_WAVES; d <<= 1) {
+				const uint32_t y = __shfl_up(inc, d, 64);
+				if (lane >= d) inc += y;
+			}
+			if (lane < ENC_WAVES) {
+				uint32_t* gb = &s_ctl[C_GBASE + (pslot * ENC_WAVES + lane) * 2];
+				lds_st(gb, excl + inc - ws);
+				asm volatile("" ::: "memory");
+				lds_st(gb + 1, it);
+			}
+		};
+		auto copy_out_prev2 = [&]() {                          // item it-2: its gbase was published during iteration it-1
+			if (!have_prev2 || p2_len == 0) return;
+			const uint32_t* gb = &s_ctl[C_GBASE + ((((it - 2) & (DF_SLOTS - 1))) * ENC_WAVES + wave) * 2];
+			lds_wait(gb + 1, it - 1, 0, A.ctrl, lane);
+			asm volatile("" ::: "memory");
+			const uint32_t base = __builtin_amdgcn_readfirstlane(lds_ld(gb));
+			wave_copy_own(s_stage0 + ((it & 1) * ENC_WAVES + wave) * WSLOT, A.out + (size_t)p2_f * A.out_stride + base, p2_len, lane);
+		};
+
+		if (!have) {                                           // drain: two more rounds for the last two items
+			if (!have_prev && !have_prev2) break;
+			copy_out_prev2();
+			if (duty) resolve_prev();
+			have_prev2 = have_prev; p2_f = p_f; p2_len = p_len;
+			have_prev = false;
+			it++;
+			continue;
+		}
+
+		PSTAMP(7);
+		const bool is_i = ((A.first_fc + f) & 3u) == 0;
+		uint8_t* wslot = s_stage0 + ((it & 1) * ENC_WAVES + wave) * WSLOT;   // free since this wave's copy-out of item it-2
+		uint8_t* scratch = wslot + 16;
+		if (new_tile) {
+			if (((A.first_fc + g.f_lo) & 3u) != 0) {           // GOP started in an earlier batch
+#pragma unroll
+				for (int r = 0; r < 4; r++) {
+					const uint2 q = *(const uint2*)(A.ientries + g.poff + r * A.w);
+					ip[2 * r] = q.x; ip[2 * r + 1] = q.y;
+				}
+			} else {
+#pragma unroll
+				for (int m = 0; m < 8; m++) ip[m] = 0;
+			}
+			if (wave == 0 && lane == 0) tk = atomicAdd(my_ctr, 1u);   // ticket of the NEXT tile, drawn a tile ahead
+		}
+		// ---- (Q) colour -> entry through the exact table, lane = (block, row)
+		uint32_t eq[16];
+#ifdef ABL_SMALLLUT
+#define LUT_OFF(c) ((lut_index(c) * 2u) & 0x1FFFFEu)
+#else
+#define LUT_OFF(c) (lut_index(c) * 2u)
+#endif
+#pragma unroll
+		for (int i = 0; i < 4; i++) {
+#ifdef ABL_NOGATHER
+			eq[i * 4 + 0] = px[i].x & 0x1FFu; eq[i * 4 + 1] = px[i].y & 0x1FFu;
+			eq[i * 4 + 2] = px[i].z & 0x1FFu; eq[i * 4 + 3] = px[i].w & 0x1FFu;
+#else
+			eq[i * 4 + 0] = (uint16_t)__builtin_amdgcn_raw_buffer_load_b16(lut_rs, LUT_OFF(px[i].x), 0, 0);
+			eq[i * 4 + 1] = (uint16_t)__builtin_amdgcn_raw_buffer_load_b16(lut_rs, LUT_OFF(px[i].y), 0, 0);
+			eq[i * 4 + 2] = (uint16_t)__builtin_amdgcn_raw_buffer_load_b16(lut_rs, LUT_OFF(px[i].z), 0, 0);
+			eq[i * 4 + 3] = (uint16_t)__builtin_amdgcn_raw_buffer_load_b16(lut_rs, LUT_OFF(px[i].w), 0, 0);
+#endif
+		}
+		PSTAMP(0);
+		// ---- while the look-ups are in flight: next item's pixels, copy-out of item it-2, look-back of item it-1.
+		// The pixel loads are issued BEHIND the look-ups (the memory counter retires in order: ahead of them they would
+		// have to land before the first entry is usable).
+		asm volatile("" ::: "memory");
+		bool have_next = true;
+		if (new_tile && wave == 0) {                           // publish the next tile's ticket to the other waves
+			if (lane == 0) {
+				const uint32_t tkv = draw_ticket(A, xcd, tk);
+				uint32_t* tw = &s_ctl[C_TICKET + ((seq + 1) & (DF_SLOTS - 1)) * 2];
+				lds_st(tw, tkv);
+				asm volatile("" ::: "memory");
+				lds_st(tw + 1, seq + 1);
+			}
+		}
+		if (f + 1 < g.f_hi) {
+			load_frame(g, A.pix + (size_t)(f + 1) * npx, px);
+		} else {
+			const uint32_t* tw = &s_ctl[C_TICKET + ((seq + 1) & (DF_SLOTS - 1)) * 2];
+			lds_wait(tw + 1, seq + 1, 0, A.ctrl, lane);
+			asm volatile("" ::: "memory");
+			const uint32_t nt = __builtin_amdgcn_readfirstlane(lds_ld(tw));
+			have_next = nt < A.total_tiles;
+			if (have_next) {
+				setup(nt, gn);
+				load_frame(gn, A.pix + (size_t)gn.f_lo * npx, px);
+			}
+		}
+		PSTAMP(2);
+		copy_out_prev2();                                      // reads slot[it & 1] BEFORE this item's scratch / emission rewrite it
+		PSTAMP(6);
+		if (duty) resolve_prev();
+		PSTAMP(3);
+		asm volatile("" ::: "memory");
+		// [block][pixel] u16 table in the wave's scratch; a lane writes its row: 8 bytes at i*512 + lane*8
+#pragma unroll
+		for (int i = 0; i < 4; i++) {
+			uint2 q;
+			q.x = eq[i * 4 + 0] | (eq[i * 4 + 1] << 16);
+			q.y = eq[i * 4 + 2] | (eq[i * 4 + 3] << 16);
+			*(uint2*)(scratch + i * 512 + lane * 8) = q;
+		}
+		PSTAMP(1);
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+		__builtin_amdgcn_wave_barrier();
+		// ---- transpose: lane = block reads its 16 entries (32 contiguous bytes), kept PACKED two per register
+		uint32_t ep[8];
+		{
+			const uint4 lo = *(const uint4*)(scratch + lane * 32), hi = *(const uint4*)(scratch + lane * 32 + 16);
+			ep[0] = lo.x; ep[1] = lo.y; ep[2] = lo.z; ep[3] = lo.w; ep[4] = hi.x; ep[5] = hi.y; ep[6] = hi.z; ep[7] = hi.w;
+		}
+		// ---- (C) block tests. count1 = CompareIFrameBlock vs the top-left entry colour
+		// (src/agmv_encode.c:302-352), count2 = ComparePFrameBlock vs the I-frame entries
+		// (src/agmv_encode.c:240-300); one matrix bit per pixel (the shifter uses the low 5 bits of its amount).
+		const uint32_t e0 = ep[0] & 0xffffu, row0 = e0 * MROW;
+		uint32_t acc1 = 0, acc2 = 0, nesc = 0;
+#pragma unroll
+		for (int m = 0; m < 8; m++) {
+			const uint32_t p = ep[m], a5 = (p >> 5) & 0x7ffu, b5 = p >> 21, bh = p >> 16;
+			const uint32_t wa = s_mtx[row0 + a5], wb = s_mtx[row0 + b5];
+			acc1 = __builtin_amdgcn_alignbit(wa >> (p & 31u), acc1, 1);
+			acc1 = __builtin_amdgcn_alignbit(wb >> (bh & 31u), acc1, 1);
+			if (M512) nesc += ((p & 0xffu) >= 127u ? 1u : 0u) + ((bh & 0xffu) >= 127u ? 1u : 0u);
+			if (!is_i) {
+				const uint32_t q = ip[m];
+				const uint32_t va = s_mtx[(q & 0xffffu) * MROW + a5], vb = s_mtx[(q >> 16) * MROW + b5];
+				acc2 = __builtin_amdgcn_alignbit(va >> (p & 31u), acc2, 1);
+				acc2 = __builtin_amdgcn_alignbit(vb >> (bh & 31u), acc2, 1);
+			}
+		}
+		const uint32_t count1 = __popc(acc1), count2 = __popc(acc2);
+		const bool copy = !is_i && count2 >= COPY_COUNT;       // COPY has priority, :465
+		const bool fill = !copy && count1 >= FILL_COUNT;
+		uint32_t len;
+		if (copy) len = 1;
+		else if (fill) len = M512 ? (2u + ((e0 & 0xffu) >= 127u ? 1u : 0u)) : 2u;
+		else len = 17u + nesc;
+		if (!g.valid) len = 0;
+
+		if (is_i) {                                            // iframe_entries = img_entry, :626-630
+#pragma unroll
+			for (int m = 0; m < 8; m++) ip[m] = ep[m];
+			if (A.ientries && (uint32_t)f == A.last_iframe && g.valid) {
+#pragma unroll
+				for (int r = 0; r < 4; r++) {
+					uint2 q;
+					q.x = ep[2 * r]; q.y = ep[2 * r + 1];
+					*(uint2*)(A.ientries + g.poff + r * A.w) = q;
+				}
+			}
+		}
+
+		// ---- byte offsets inside the wave; the last wave to arrive publishes the tile's aggregate
+		const uint32_t incl = wave_incl_scan(len, lane);
+		const uint32_t wtot = __builtin_amdgcn_readlane(incl, 63);
+		uint32_t arrived = 0;
+		if (lane == 63) {
+			lds_st(&s_ctl[C_WSUM + slot * ENC_WAVES + wave], (tag << 16) | incl);
+			asm volatile("" ::: "memory");
+			arrived = atomicAdd(&s_ctl[C_ARRIVE + slot], 1u);
+		}
+		arrived = __builtin_amdgcn_readlane(arrived, 63);
+		if (arrived == ENC_WAVES - 1) {
+			const uint32_t ws = lane < ENC_WAVES ? (lds_ld(&s_ctl[C_WSUM + slot * ENC_WAVES + lane]) & 0xffffu) : 0u;
+			const uint32_t total = wave_sum(ws);
+			if (lane == 0) {
+				lds_st(&s_ctl[C_ARRIVE + slot], 0u);
+				__hip_atomic_store(A.status + (size_t)f * A.tpf + g.tile, (g.tile == 0 ? ST_PREFIX : ST_AGG) | total,
+				                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				lds_st(&s_ctl[C_TTOTAL + slot], (tag << 16) | total);
+			}
+		}
+		PSTAMP(4);
+		// ---- (E) emit this block's bytes into the wave's stage slot
+#if ENC_PKEMIT
+		// Codes are built two at a time in packed 16-bit lanes and written as {code, index} byte PAIRS at byte-granular
+		// LDS addresses (gfx950 runs DS in unaligned mode): when an entry has no escape byte its pair's second byte is
+		// overwritten by the next pair, and the one byte a block may spill past its end is the next block's flag --
+		// which is why the flags are written last.  The LDS unit executes a wave's writes in program order.
+		if (g.valid) {
+			uint8_t* sp = wslot + 16 + incl - len;
+			if (!copy && !fill) {
+				if (M512) {
+					uint32_t n = 0;                                // escape bytes so far
+#pragma unroll
+					for (int m = 0; m < 8; m++) {
+						const uint32_t p = ep[m], idx2 = p & 0x00FF00FFu;
+						const u16x2 c2 = __builtin_elementwise_min(__builtin_bit_cast(u16x2, idx2), __builtin_bit_cast(u16x2, 0x007F007Fu));
+						const uint32_t code2 = ((p >> 1) & 0x00800080u) | __builtin_bit_cast(uint32_t, c2);   // :395-401
+						const uint32_t w = __builtin_amdgcn_perm(code2, p, 0x02060004u);   // code_lo, idx_lo, code_hi, idx_hi
+						const uint32_t e2 = idx2 + 0x00810081u;    // bit 8 / bit 24: index >= 127
+						*(u16u*)(sp + n + (1 + 2 * m)) = (uint16_t)w;
+						n += (e2 >> 8) & 1u;
+						*(u16u*)(sp + n + (2 + 2 * m)) = (uint16_t)(w >> 16);
+						n += e2 >> 24;
+					}
+				} else {
+#pragma unroll
+					for (int m = 0; m < 4; m++)                    // :428-429
+						*(u32u*)(sp + 1 + 4 * m) = __builtin_amdgcn_perm(ep[2 * m + 1], ep[2 * m], 0x06040200u);
+				}
+			} else if (fill) {
+				if (M512) {
+					const uint32_t idx = e0 & 0xffu, p7 = (e0 >> 1) & 0x80u;
+					*(u16u*)(sp + 1) = (uint16_t)(p7 | (idx < 127u ? idx : 127u) | (idx << 8));   // :382-388
+				} else {
+					sp[1] = (uint8_t)e0;                           // :421
+				}
+			}
+			asm volatile("" ::: "memory");
+			sp[0] = copy ? COPY_FLAG : (fill ? FILL_FLAG : NORMAL_FLAG);
+		}
+#else
+		if (g.valid) {
+			uint8_t* sp = wslot + 16 + incl - len;
+			if (copy) {
+				sp[0] = COPY_FLAG;
+			} else if (fill) {
+				sp[0] = FILL_FLAG;
+				if (M512) {
+					const uint32_t idx = e0 & 0xffu, p7 = (e0 >> 1) & 0x80u;
+					sp[1] = (uint8_t)(p7 | (idx < 127u ? idx : 127u));        // :382-388
+					if (idx >= 127u) sp[2] = (uint8_t)idx;
+				} else {
+					sp[1] = (uint8_t)e0;                                       // :421
+				}
+			} else {
+				sp[0] = NORMAL_FLAG;
+				uint32_t pos = 1;
+#pragma unroll
+				for (int m = 0; m < 8; m++) {
+#pragma unroll
+					for (int hf = 0; hf < 2; hf++) {
+						const uint32_t ek = hf ? ep[m] >> 16 : ep[m] & 0xffffu;
+						if (M512) {
+							const uint32_t idx = ek & 0xffu, p7 = (ek >> 1) & 0x80u;
+							sp[pos] = (uint8_t)(p7 | (idx < 127u ? idx : 127u));    // :395-401
+							if (idx >= 127u) sp[pos + 1] = (uint8_t)idx;
+							pos += 1u + (idx >= 127u ? 1u : 0u);
+						} else {
+							sp[pos++] = (uint8_t)ek;                               // :428-429
+						}
+					}
+				}
+			}
+		}
+#endif
+		PSTAMP(5);
+
+		// ---- next item
+		have_prev2 = have_prev; p2_f = p_f; p2_len = p_len;
+		have_prev = true; p_tile = g.tile; p_f = f; p_len = wtot;
+		it++;
+		if (f + 1 < g.f_hi) {
+			f++; new_tile = false;
+		} else {
+			have = have_next;
+			if (have) { g = gn; f = g.f_lo; }
+			seq++; new_tile = true;
+		}
+	}
+#ifdef ENC_PROF
+	if (lane == 0)
+		for (int k = 0; k < 8; k++) atomicAdd(A.ctrl + 32 + k, prof[k] >> 10);
+#endif
+}
+#endif
 
 // ----------------------------------------------------------------------------------------------
 // decode side
@@ -1598,7 +2141,7 @@ extern "C" int agmv_hip_set_palette(agmv_hip_ctx* c, const uint32_t p0[256], con
 	if (p1) memcpy(pal + 256, p1, 1024); else memset(pal + 256, 0, 1024);
 	CK(hipMemcpyAsync(c->d_pal, pal, sizeof(pal), hipMemcpyHostToDevice, s));
 	CK(hipStreamSynchronize(s));                              // pal[] is a stack buffer
-	hipLaunchKernelGGL(k_lut_build, dim3(LUT_ENTRIES / 256), dim3(256), 0, s, c->d_pal, mode512 ? 1 : 0, c->d_lut);
+	hipLaunchKernelGGL(k_lut_build, dim3(LUT_COLOURS / 256), dim3(256), 0, s, c->d_pal, mode512 ? 1 : 0, c->d_lut);
 	CK(hipGetLastError());
 	hipLaunchKernelGGL(k_mtx_build, dim3((512 * MROW + 255) / 256), dim3(256), 0, s, c->d_pal, c->d_mtx);
 	CK(hipGetLastError());
@@ -1651,6 +2194,8 @@ extern "C" int agmv_hip_encode_frames_dev(agmv_hip_ctx* c, const uint32_t* d_pix
 	A.first_fc = first_fc; A.phase = first_fc & 3u;
 	A.n_groups = (n_frames + A.phase + 3) / 4;
 	A.total_tiles = A.n_groups * A.tpf;
+	A.n_xcd = c->n_cu >= 64 ? (uint32_t)c->n_cu / 32u : 1u;      // MI355X: 256 CUs in 8 XCDs
+	if (A.n_xcd > 16) A.n_xcd = 16;
 	if (A.phase != 0 && !d_ientries) {
 		snprintf(g_err, sizeof(g_err), "agmv_hip: batch starts inside a GOP (frame_count %u) but no I-frame entries were supplied", first_fc);
 		return -1;
@@ -1670,7 +2215,11 @@ extern "C" int agmv_hip_encode_frames_dev(agmv_hip_ctx* c, const uint32_t* d_pix
 	CK(hipMemsetAsync(c->d_ctrl, 0, CTRL_BYTES, s));
 	uint32_t grid = (uint32_t)c->enc_grid;
 	if (grid > A.total_tiles) grid = A.total_tiles;
+#if ENC_DF
+	const size_t lds = (size_t)(c->mode512 ? 512 : 256) * MROW * 4 + ENC_LDS_EXTRA;
+#else
 	const size_t lds = (size_t)(c->mode512 ? 512 : 256) * MROW * 4 + 2 * STAGE_SZ + 128;
+#endif
 	if (c->mode512) CK(hipFuncSetAttribute((const void*)k_encode<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
 	else CK(hipFuncSetAttribute((const void*)k_encode<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
 	ev_mark(c, 0, s);
@@ -1687,6 +2236,16 @@ extern "C" int agmv_hip_check(agmv_hip_ctx* c, void* stream)
 	uint32_t ctrl[4] = {0, 0, 0, 0};
 	CK(hipStreamSynchronize((hipStream_t)stream));
 	CK(hipMemcpy(ctrl, c->d_ctrl, 16, hipMemcpyDeviceToHost));
+#ifdef ENC_PROF
+	{
+		uint32_t pr[8];
+		CK(hipMemcpy(pr, c->d_ctrl + 32, 32, hipMemcpyDeviceToHost));
+		double tot = 0;
+		for (int k = 0; k < 8; k++) tot += pr[k];
+		fprintf(stderr, "k_encode phases (%% of wave time): issue %.1f | look-up wait+stores %.1f | prefetch+ticket %.1f | duty %.1f | classify+scan %.1f | emit %.1f | copy-out %.1f | loop top %.1f\n",
+		        100 * pr[0] / tot, 100 * pr[1] / tot, 100 * pr[2] / tot, 100 * pr[3] / tot, 100 * pr[4] / tot, 100 * pr[5] / tot, 100 * pr[6] / tot, 100 * pr[7] / tot);
+	}
+#endif
 	if (ctrl[1]) { snprintf(g_err, sizeof(g_err), "agmv_hip: look-back timed out inside k_encode (device error word %u)", ctrl[1]); return -2; }
 	return 0;
 }
