@@ -9,7 +9,8 @@
 //   k_encode        loops A+B of AGMV_EncodeFrame fused (src/agmv_encode.c:552-565, 240-527):
 //                   one lane = one 4x4 block carried through the 4 frames of its GOP, one
 //                   workgroup = 512 consecutive blocks; per-frame byte offsets by a decoupled
-//                   look-back over tiles (single pass over the pixels)
+//                   look-back over tiles (single pass over the pixels); no workgroup barrier in
+//                   the steady state -- the waves exchange tagged LDS words
 //   k_parse_serial  block entry positions of a decompressed bitstream (src/agmv_decode.c:224-322)
 //   k_decode        block -> RGB reconstruction (src/agmv_decode.c:249-319, 350-396, 401-405)
 //   k_fixup         sequential repair of blocks whose value depends on an earlier GOP
@@ -55,20 +56,8 @@ extern "C" const char* agmv_hip_last_error(void) { return g_err; }
 #ifndef ENC_WPE
 #define ENC_WPE 4
 #endif
-#ifndef ENC_DF
-#define ENC_DF 0
-#endif
-#ifndef ENC_XCD
-#define ENC_XCD 0
-#endif
-#ifndef ENC_BAND
-#define ENC_BAND 4
-#endif
 #ifndef ENC_PIXAUX
-#define ENC_PIXAUX 0
-#endif
-#ifndef ENC_PKEMIT
-#define ENC_PKEMIT 0
+#define ENC_PIXAUX 2          /* cache policy of the pixel loads: 2 = nt (streamed once; keeps L2 for the table), 0 = default */
 #endif
 constexpr int ENC_T = ENC_T_OVERRIDE;          // threads per encode workgroup = 4x4 blocks per tile
 constexpr int ENC_WAVES = ENC_T / 64;
@@ -83,7 +72,7 @@ constexpr int DEC_T = DEC_T_OVERRIDE;          // threads per decode workgroup
 constexpr int DEC_STAGE = DEC_T * DEC_BPB;   // LDS window for a tile's bitstream bytes in ONE frame (24 B per block; beyond it bytes come from global memory); x4 frames = 24 KB, 5 workgroups per CU
 constexpr int DEC_SR = DEC_STAGE / 4 / DEC_T;   // dwords of the window each lane carries from global memory to LDS
 #ifndef LUT_SPARSE
-#define LUT_SPARSE 0
+#define LUT_SPARSE 1
 #endif
 constexpr uint32_t LUT_COLOURS = 1u << 24;
 constexpr uint32_t LUT_ENTRIES = LUT_SPARSE ? (1u << 28) : (1u << 24);   // index space of the table (see lut_index)
@@ -213,7 +202,7 @@ struct EncArgs {
 	uint32_t* ctrl;
 	uint16_t* ientries;
 	unsigned long long out_stride;
-	uint32_t n_frames, w, h, bw, nblk, tpf, first_fc, phase, n_groups, last_iframe, total_tiles, n_xcd;
+	uint32_t n_frames, w, h, bw, nblk, tpf, first_fc, phase, n_groups, last_iframe, total_tiles;
 };
 
 // Workgroup barrier that orders LDS only.  __syncthreads() also carries a global-memory fence, i.e. an
@@ -285,369 +274,10 @@ __device__ __forceinline__ uint32_t lookback(unsigned long long* st, int tile, i
 	}
 }
 
-// cooperative copy of `total` staged bytes to the frame bitstream at byte offset `base`:
-// dword stores on global-aligned dwords (staged byte i lives at stage byte 4+i), bytes at the
-// two ragged ends (which share a dword with the neighbouring tiles).
-__device__ __forceinline__ void copy_out(const uint8_t* stage, uint8_t* gdst, uint32_t total, int tid)
-{
-	const uint32_t s = (uint32_t)((uintptr_t)gdst & 3u);
-	uint8_t* g0 = gdst - s;
-	const uint32_t ndw = (s + total + 3u) >> 2;
-	const uint32_t* s32 = (const uint32_t*)stage;
-	for (uint32_t j = tid; j < ndw; j += ENC_T) {
-		const int lo_i = (int)(4u * j) - (int)s;              // staged index of this dword's byte 0
-		if (lo_i >= 0 && (uint32_t)lo_i + 4u <= total) {
-			const uint32_t lo = s32[j], hi = s32[j + 1];
-			*(uint32_t*)(g0 + 4u * j) = s ? __builtin_amdgcn_alignbyte(hi, lo, 4u - s) : hi;
-		} else {
-#pragma unroll
-			for (int q = 0; q < 4; q++) {
-				const int i = lo_i + q;
-				if (i >= 0 && (uint32_t)i < total) g0[4u * j + q] = stage[4 + i];
-			}
-		}
-	}
-}
-
 constexpr int WBLK = 64;                                       // blocks per wave = slice of the workgroup tile
-constexpr int WSLICE = WBLK * 33;                              // stage bytes a wave's blocks can produce (2112)
-constexpr int STAGE_SZ = 4 + ENC_T * 33 + 12;                  // front pad + worst case + tail pad
-static_assert(STAGE_SZ % 16 == 0 && WSLICE % 16 == 0, "stage buffers / slices must stay 16-byte aligned");
-static_assert(WSLICE >= WBLK * 16 * 2 + 16, "the entry transpose scratch aliases the wave's stage slice");
-constexpr size_t CTRL_BYTES = 256;                             // [0] ticket, [1] error, [16..31] per-XCD tickets
+constexpr size_t CTRL_BYTES = 256;                             // [0] ticket, [1] error, [32..39] phase stamps (ENC_PROF builds)
 
-// copy staged bytes [lo, hi) of a tile to the frame bitstream (gdst = address of staged byte 0), one wave:
-// dword stores on global-aligned dwords (staged byte i lives at stage byte 4+i), bytes at the ragged ends.
-__device__ __forceinline__ void wave_copy_out(const uint8_t* stage, uint8_t* gdst, uint32_t total, int wave, int lane)
-{
-	// The tile's bytes [0,total) sit at stage+4; the workgroup writes them to gdst as GLOBAL-aligned dwords.  Wave w
-	// writes the dwords whose first byte lies in its slice [w*WSLICE, (w+1)*WSLICE): a dword that straddles the
-	// slice end reads <= 3 bytes of the next slice, which that wave's transposes never overwrite (they start 12
-	// bytes in).  Only the tile's first and last dword can be partial (byte stores).
-	const uint32_t lo = (uint32_t)wave * WSLICE;
-	if (lo >= total) return;
-	const uint32_t hi = lo + WSLICE < total ? lo + WSLICE : total;
-	const uint32_t s = (uint32_t)((uintptr_t)gdst & 3u);
-	uint8_t* g0 = gdst - s;
-	const uint32_t d_lo = wave == 0 ? 0u : (lo + s + 3u) >> 2, d_hi = (hi + s + 3u) >> 2;
-	const uint32_t* s32 = (const uint32_t*)stage;
-	for (uint32_t d = d_lo + lane; d < d_hi; d += 64) {
-		const int t0 = (int)(4u * d) - (int)s;                 // tile byte held by the dword's first byte
-		if (t0 >= 0 && (uint32_t)t0 + 4u <= total) {
-			const uint32_t a = s32[d], b = s32[d + 1];
-			*(uint32_t*)(g0 + 4u * d) = s ? __builtin_amdgcn_alignbyte(b, a, 4u - s) : b;
-		} else {
-#pragma unroll
-			for (int q = 0; q < 4; q++) {
-				const int t = t0 + q;
-				if (t >= 0 && (uint32_t)t < total) g0[4u * d + q] = stage[4 + t];
-			}
-		}
-	}
-}
-
-#if !ENC_DF
-// K1.  One workgroup = one tile of 512 consecutive 4x4 blocks (8 waves x 64 blocks), carried through the
-// <=4 frames of one GOP; one lane owns one block for classification/emission.  Software-pipelined by one frame:
-//   iteration f:  (Q) quantise with lane = (block, row): wide row loads, each LUT gather instruction covers a
-//                     64x4-pixel patch (few 4x4x4 colour-cube lines); entries are transposed to lane = block
-//                     through the wave's own slice of stage[f&1] (no workgroup barrier needed)
-//                 (C) classify: FILL / COPY / NORMAL from one bit-matrix bit per pixel; wave scan of lengths
-//                 (L) one wave (rotating duty) resolves the decoupled look-back of frame f-1 while its own look-ups
-//                     are in flight (the status window is loaded ahead of them)
-//                 ONE barrier; publish the tile aggregate of frame f; (E) emit bytes into stage[f&1]; every wave
-//                 copies its slice of stage[(f-1)&1] out.
-template <bool M512>
-__global__ __launch_bounds__(ENC_T, ENC_WPE) void k_encode(EncArgs A)
-{
-	constexpr int NROWS = M512 ? 512 : 256;
-	extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-	uint32_t* s_mtx = (uint32_t*)smem;                         // NROWS * MROW dwords
-	uint8_t* s_stage0 = smem + NROWS * MROW * 4;               // two stage buffers
-	uint32_t* s_misc = (uint32_t*)(s_stage0 + 2 * STAGE_SZ);   // wave sums x2, then base x2, then the ticket
-	constexpr int MISC_BASE = 2 * ENC_WAVES, MISC_TICKET = MISC_BASE + 2;
-	static_assert(MISC_TICKET < 32, "s_misc has 32 dwords");
-
-	const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-	const uint32_t npx = A.w * A.h;
-	const uint32_t jb = lane >> 2, prow = lane & 3;            // quantise phase: lane = (block jb of 16, row prow)
-	const __amdgpu_buffer_rsrc_t lut_rs = __builtin_amdgcn_make_buffer_rsrc((void*)A.lut, 0, (int)(LUT_ENTRIES * 2u), 0x00020000);
-
-	for (int i = tid; i < NROWS * MROW; i += ENC_T) s_mtx[i] = A.mtx[i];
-
-	for (;;) {
-		__syncthreads();                                       // matrix ready / previous tile fully drained
-		if (tid == 0) s_misc[MISC_TICKET] = atomicAdd(A.ctrl, 1u);
-		__syncthreads();
-		const uint32_t t = s_misc[MISC_TICKET];
-		if (t >= A.total_tiles) break;
-		// tile-major ticket order: consecutive tickets are the SAME tile of different GOPs, so a tile's
-		// predecessors (same GOP, lower tile) are n_groups tickets older -> mostly finished and already
-		// carrying an inclusive prefix when the look-back reads them.
-		// (Bands of 4..32 GOPs -- fewer frames touched at a time -- were measured: 1.04..0.96 ms against 0.95.)
-		const uint32_t tile = t / A.n_groups, group = t - tile * A.n_groups;
-		const int f_lo = group == 0 ? 0 : (int)(group * 4 - A.phase);
-		int f_hi = (int)(group * 4 - A.phase) + 4;
-		if (f_hi > (int)A.n_frames) f_hi = (int)A.n_frames;
-
-		// geometry: ONE integer division per wave (of its first block, wave-uniform); lane positions follow by adding
-		// and wrapping at the end of a block row (no per-lane divisions)
-		const uint32_t wbase = tile * ENC_T + wave * WBLK;      // first block of this wave
-		const uint32_t wb_c = wbase < A.nblk ? wbase : A.nblk - 1;
-		const uint32_t wby = __builtin_amdgcn_readfirstlane(wb_c / A.bw), wbx = wb_c - wby * A.bw;
-		auto locate = [&](uint32_t B, uint32_t& qx, uint32_t& qy) {   // block index (>= wb_c) -> block column / row
-			if (B >= A.nblk) B = A.nblk - 1;                   // blocks past the frame re-use the last valid one
-			qx = wbx + (B - wb_c); qy = wby;
-			while (qx >= A.bw) { qx -= A.bw; qy++; }
-		};
-		// lane-as-block view (classification, emission, I-frame entry plane)
-		const uint32_t blk = wbase + lane;
-		const bool valid = blk < A.nblk;
-		uint32_t bx, by;
-		locate(blk, bx, by);
-		const uint32_t poff = by * 4 * A.w + bx * 4;           // top-left pixel of the block
-
-		// quantise view, lane = (block, row): load i (0..3) fetches row `prow` (16 bytes) of block wbase + 16i + jb, so
-		// one instruction reads four 256-byte row segments of 16 adjacent blocks (1 KiB, full lines) and each of its
-		// four pixel columns is a 64x4-pixel patch for the LUT gather.  A wave inside one block row uses immediate
-		// offsets, one crossing a single row boundary adds 3*w past it, anything else (frames narrower than 64 blocks,
-		// the ragged end of the frame) locates each of its four blocks.
-		const uint32_t B0 = wbase + jb;
-		uint32_t qx0, qy0;
-		locate(B0, qx0, qy0);
-		const uint32_t p0b = ((qy0 * 4 + prow) * A.w + qx0 * 4) * 4u, w3b = 12u * A.w;
-		const int path = (wbase + WBLK > A.nblk || wbx + WBLK > 2 * A.bw) ? 2 : (wbx + WBLK > A.bw ? 1 : 0);
-		auto load_frame = [&](const uint32_t* fp, uint4 (&dst)[4]) {
-			// uniform 128-bit descriptor per frame + one 32-bit byte offset per lane
-			const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)fp, 0, (int)(npx * 4u), 0x00020000);
-			if (path == 0) {
-#pragma unroll
-				for (int i = 0; i < 4; i++) dst[i] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rs, p0b + 256 * i, 0, 0));
-			} else if (path == 1) {
-#pragma unroll
-				for (int i = 0; i < 4; i++)
-					dst[i] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rs, p0b + 256 * i + (qx0 + 16 * i >= A.bw ? w3b : 0u), 0, 0));   // past the end of B0's own block row
-			} else {
-#pragma unroll
-				for (int i = 0; i < 4; i++) {
-					uint32_t qx, qy;
-					locate(B0 + 16 * i, qx, qy);
-					dst[i] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rs, ((qy * 4 + prow) * A.w + qx * 4) * 4u, 0, 0));
-				}
-			}
-		};
-
-		uint32_t ip[8];                                        // the GOP's I-frame entries of this block, two u16 per register
-		if (((A.first_fc + f_lo) & 3u) != 0) {                 // GOP started in an earlier batch
-#pragma unroll
-			for (int r = 0; r < 4; r++) {
-				const uint2 q = *(const uint2*)(A.ientries + poff + r * A.w);
-				ip[2 * r] = q.x; ip[2 * r + 1] = q.y;
-			}
-		} else {
-#pragma unroll
-			for (int m = 0; m < 8; m++) ip[m] = 0;
-		}
-
-		uint4 px[4];
-		load_frame(A.pix + (size_t)f_lo * npx, px);
-
-		uint32_t total_prev = 0;
-		for (int f = f_lo; f <= f_hi; f++) {
-			const bool have_cur = f < f_hi, have_prev = f > f_lo;
-			// (L) the look-back of frame f-1 is the duty of ONE wave (rotating), done while its own table look-ups are
-			// in flight: the status window is loaded first, so it has landed when the look-ups have (in-order counter)
-			const bool duty = have_prev && wave == (f % ENC_WAVES);
-			unsigned long long pre = ST_PREFIX;
-#ifndef ABL_NOSTATUS
-			if (duty && tile != 0) pre = st_load(A.status + (size_t)(f - 1) * A.tpf, (int)tile - 1 - lane);
-#endif
-			auto resolve_prev = [&]() {                            // tile offset of frame f-1 -> s_misc, usize of the frame
-				unsigned long long* st = A.status + (size_t)(f - 1) * A.tpf;
-				uint32_t excl = 0;
-#if defined(ABL_NOLOOKBACK) || defined(ABL_NOSTATUS)
-				if (false) {
-#else
-				if (tile != 0) {
-#endif
-					excl = lookback(st, (int)tile, lane, A.ctrl, pre);
-					if (lane == 0)
-						__hip_atomic_store(st + tile, ST_PREFIX | (unsigned long long)(excl + total_prev),
-						                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-				}
-				if (lane == 0) {
-					s_misc[MISC_BASE + ((f - 1) & 1)] = excl;
-					if (tile == A.tpf - 1) A.sizes[f - 1] = excl + total_prev;   // usize of the frame
-				}
-			};
-			auto copy_out_prev = [&]() {                           // after the barrier: base of f-1 known, its stage complete
-#ifdef ABL_NOEMIT
-				if (total_prev != 0xFFFFFFFFu) return;
-#endif
-				const uint32_t base = s_misc[MISC_BASE + ((f - 1) & 1)];
-#ifdef ABL_NOCOPYOUT
-				if (base != 0xFFFFFFF0u) return;
-#endif
-				wave_copy_out(s_stage0 + ((f - 1) & 1) * STAGE_SZ, A.out + (size_t)(f - 1) * A.out_stride + base, total_prev, wave, lane);
-			};
-			uint32_t total = 0;
-			if (have_cur) {
-				const bool is_i = ((A.first_fc + f) & 3u) == 0;
-				uint8_t* stage = s_stage0 + (f & 1) * STAGE_SZ;
-				uint8_t* scratch = stage + 4 + wave * WSLICE;      // this wave's slice: free since its copy-out of f-2
-				// ---- (Q) colour -> entry through the exact table, lane = (block, row)
-				uint32_t eq[16];
-#pragma unroll
-				for (int i = 0; i < 4; i++) {
-#ifdef ABL_NOGATHER
-					eq[i * 4 + 0] = px[i].x & 0x1FFu; eq[i * 4 + 1] = px[i].y & 0x1FFu;
-					eq[i * 4 + 2] = px[i].z & 0x1FFu; eq[i * 4 + 3] = px[i].w & 0x1FFu;
-#else
-					eq[i * 4 + 0] = (uint16_t)__builtin_amdgcn_raw_buffer_load_b16(lut_rs, lut_index(px[i].x) * 2u, 0, 0);
-					eq[i * 4 + 1] = (uint16_t)__builtin_amdgcn_raw_buffer_load_b16(lut_rs, lut_index(px[i].y) * 2u, 0, 0);
-					eq[i * 4 + 2] = (uint16_t)__builtin_amdgcn_raw_buffer_load_b16(lut_rs, lut_index(px[i].z) * 2u, 0, 0);
-					eq[i * 4 + 3] = (uint16_t)__builtin_amdgcn_raw_buffer_load_b16(lut_rs, lut_index(px[i].w) * 2u, 0, 0);
-#endif
-				}
-				// [block][pixel] u16 table in the wave's scratch; a lane writes its row: 8 bytes at i*512 + lane*8
-#pragma unroll
-				for (int i = 0; i < 4; i++) {
-					uint2 q;
-					q.x = eq[i * 4 + 0] | (eq[i * 4 + 1] << 16);
-					q.y = eq[i * 4 + 2] | (eq[i * 4 + 3] << 16);
-					*(uint2*)(scratch + 12 + i * 512 + lane * 8) = q;      // +12: 16-byte alignment of the b128 reads below
-				}
-				// prefetch the next frame of the GOP -- pinned BEHIND the table look-ups: the memory counter retires in
-				// order, so pixel loads issued ahead of them would have to land (HBM latency) before the first entry is usable
-				asm volatile("" ::: "memory");
-				if (f + 1 < f_hi) load_frame(A.pix + (size_t)(f + 1) * npx, px);
-				if (duty) resolve_prev();
-				__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-				__builtin_amdgcn_wave_barrier();
-				// ---- transpose: lane = block reads its 16 entries (32 contiguous bytes), kept PACKED two per register
-				uint32_t ep[8];
-				{
-					const uint4 lo = *(const uint4*)(scratch + 12 + lane * 32), hi = *(const uint4*)(scratch + 12 + lane * 32 + 16);
-					ep[0] = lo.x; ep[1] = lo.y; ep[2] = lo.z; ep[3] = lo.w; ep[4] = hi.x; ep[5] = hi.y; ep[6] = hi.z; ep[7] = hi.w;
-				}
-				// ---- (C) block tests. count1 = CompareIFrameBlock vs the top-left entry colour
-				// (src/agmv_encode.c:302-352), count2 = ComparePFrameBlock vs the I-frame entries
-				// (src/agmv_encode.c:240-300); one matrix bit per pixel (the shifter uses the low 5 bits of its amount).
-				const uint32_t e0 = ep[0] & 0xffffu, row0 = e0 * MROW;
-				uint32_t acc1 = 0, acc2 = 0, nesc = 0;
-#pragma unroll
-				for (int m = 0; m < 8; m++) {
-					const uint32_t p = ep[m], a5 = (p >> 5) & 0x7ffu, b5 = p >> 21, bh = p >> 16;
-#ifdef ABL_NOCMP
-					const uint32_t wa = p * 0x9E3779B1u, wb = bh * 0x9E3779B1u;
-#else
-					const uint32_t wa = s_mtx[row0 + a5], wb = s_mtx[row0 + b5];
-#endif
-					acc1 = __builtin_amdgcn_alignbit(wa >> (p & 31u), acc1, 1);
-					acc1 = __builtin_amdgcn_alignbit(wb >> (bh & 31u), acc1, 1);
-					if (M512) nesc += ((p & 0xffu) >= 127u ? 1u : 0u) + ((bh & 0xffu) >= 127u ? 1u : 0u);
-					if (!is_i) {
-						const uint32_t q = ip[m];
-#ifdef ABL_NOCMP
-						const uint32_t va = (p ^ q) * 0x9E3779B1u, vb = (bh ^ (q >> 16)) * 0x9E3779B1u;
-#else
-						const uint32_t va = s_mtx[(q & 0xffffu) * MROW + a5], vb = s_mtx[(q >> 16) * MROW + b5];
-#endif
-						acc2 = __builtin_amdgcn_alignbit(va >> (p & 31u), acc2, 1);
-						acc2 = __builtin_amdgcn_alignbit(vb >> (bh & 31u), acc2, 1);
-					}
-				}
-				const uint32_t count1 = __popc(acc1), count2 = __popc(acc2);
-				const bool copy = !is_i && count2 >= COPY_COUNT;   // COPY has priority, :465
-				const bool fill = !copy && count1 >= FILL_COUNT;
-				uint32_t len;
-				if (copy) len = 1;
-				else if (fill) len = M512 ? (2u + ((e0 & 0xffu) >= 127u ? 1u : 0u)) : 2u;
-				else len = 17u + nesc;
-				if (!valid) len = 0;
-
-				if (is_i) {                                        // iframe_entries = img_entry, :626-630
-#pragma unroll
-					for (int m = 0; m < 8; m++) ip[m] = ep[m];
-					if (A.ientries && (uint32_t)f == A.last_iframe && valid) {
-#pragma unroll
-						for (int r = 0; r < 4; r++) {
-							uint2 q;
-							q.x = ep[2 * r]; q.y = ep[2 * r + 1];
-							*(uint2*)(A.ientries + poff + r * A.w) = q;
-						}
-					}
-				}
-
-				// ---- byte offsets inside the tile: wave scan -> workgroup scan
-				uint32_t* wsum = s_misc + (f & 1) * ENC_WAVES;
-				const uint32_t incl = wave_incl_scan(len, lane);
-				if (lane == 63) wsum[wave] = incl;
-				lds_barrier();                                     // the ONE barrier of the frame: wave sums, base of f-1, scratch slices done
-				uint32_t woff = 0;
-#pragma unroll
-				for (int i = 0; i < ENC_WAVES; i++) {
-					uint32_t s = wsum[i];
-					if (i < wave) woff += s;
-					total += s;
-				}
-#ifndef ABL_NOSTATUS
-				if (tid == 0) {
-					unsigned long long v = (tile == 0 ? ST_PREFIX : ST_AGG) | total;
-					__hip_atomic_store(A.status + (size_t)f * A.tpf + tile, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-				}
-#endif
-				// ---- (E) emit this block's bytes into the LDS stage (independent of the global base)
-#ifdef ABL_NOEMIT
-				if (valid && len == 0xFFFFu) {
-#else
-				if (valid) {
-#endif
-					uint8_t* sp = stage + 4 + woff + incl - len;
-					if (copy) {
-						sp[0] = COPY_FLAG;
-					} else if (fill) {
-						sp[0] = FILL_FLAG;
-						if (M512) {
-							const uint32_t idx = e0 & 0xffu, p7 = (e0 >> 1) & 0x80u;
-							sp[1] = (uint8_t)(p7 | (idx < 127u ? idx : 127u));        // :382-388
-							if (idx >= 127u) sp[2] = (uint8_t)idx;
-						} else {
-							sp[1] = (uint8_t)e0;                                       // :421
-						}
-					} else {
-						sp[0] = NORMAL_FLAG;
-						uint32_t pos = 1;
-#pragma unroll
-						for (int m = 0; m < 8; m++) {
-#pragma unroll
-							for (int hf = 0; hf < 2; hf++) {
-								const uint32_t ek = hf ? ep[m] >> 16 : ep[m] & 0xffffu;
-								if (M512) {
-									const uint32_t idx = ek & 0xffu, p7 = (ek >> 1) & 0x80u;
-									sp[pos] = (uint8_t)(p7 | (idx < 127u ? idx : 127u));    // :395-401
-									if (idx >= 127u) sp[pos + 1] = (uint8_t)idx;
-									pos += 1u + (idx >= 127u ? 1u : 0u);
-								} else {
-									sp[pos++] = (uint8_t)ek;                               // :428-429
-								}
-							}
-						}
-					}
-				}
-				if (have_prev) copy_out_prev();
-			} else {
-				if (duty) resolve_prev();                          // drain iteration: nothing to overlap it with
-				lds_barrier();
-				copy_out_prev();
-			}
-			total_prev = total;
-		}
-	}
-}
-
-#else
-// K1 (barrier-free form).  One workgroup = one tile of ENC_T consecutive 4x4 blocks (ENC_WAVES waves x 64 blocks), one
+// K1.  Barrier-free dataflow form.  One workgroup = one tile of ENC_T consecutive 4x4 blocks (ENC_WAVES waves x 64 blocks), one
 // lane = one block for classification/emission, carried through the <=4 frames of its GOP.  The stream of
 // (tile, frame) items a workgroup processes is ONE software pipeline that runs across tile switches; the waves of a
 // workgroup never meet at a barrier inside it -- they exchange single tagged LDS words:
@@ -662,9 +292,10 @@ __global__ __launch_bounds__(ENC_T, ENC_WPE) void k_encode(EncArgs A)
 //   item `it`, duty wave (rotating): decoupled look-back of item it-1 across tiles (status window prefetched ahead
 //                               of the look-ups), then gbase[it-1][w] = tile offset + bytes of the lower waves.
 // Waves therefore drift apart by up to ~1.5 items, and the phases (look-up issue, look-up wait, LDS, VALU) of the
-// waves sharing a SIMD interleave instead of lining up behind a barrier.  Control words live in 4 slots (it & 3): a
+// waves sharing a SIMD interleave instead of lining up behind a barrier.  Control words live in 8 slots (it & 7): a
 // wave can finish item `it` only after gbase[it-1] exists, i.e. after EVERY wave has published wsum[it-1]; so when a
-// slot is rewritten for item it+1 all waves have finished item it-2 and with it every read of item it-3's words.
+// slot is rewritten for item it+1 all waves have finished item it-2 and with it every read of item it-3's words
+// (4 slots would do; 8 leave room for a copy-out that lags two items).
 constexpr int DF_SLOTS = 8;
 constexpr int WSLOT = 16 + WBLK * 33 + 16;                     // a wave's stage slot: front pad + worst case + tail pad
 static_assert(WSLOT % 16 == 0 && WSLOT >= 16 + WBLK * 16 * 2, "slot alignment / transpose scratch");
@@ -699,63 +330,21 @@ __device__ __forceinline__ uint32_t lds_wait(const uint32_t* p, uint32_t tag, in
 	return v;
 }
 
-// copy the `total` bytes staged at slot+16 to gdst (one wave): dword stores on GLOBAL-aligned dwords, byte stores at
-// the two ragged ends (which share a dword with the neighbouring waves / tiles)
+// copy the `total` bytes staged at slot+16 to gdst (one wave): dword stores on GLOBAL-aligned dwords, read from the
+// stage at byte-granular LDS addresses (DS unaligned mode); the <= 3 bytes before the first and after the last aligned
+// dword (which share a dword with the neighbouring waves / tiles) go out as byte stores from eight lanes in one step
 __device__ __forceinline__ void wave_copy_own(const uint8_t* slot, uint8_t* gdst, uint32_t total, int lane)
 {
 	const uint32_t s = (uint32_t)((uintptr_t)gdst & 3u);
-	uint8_t* g0 = gdst - s;
-	const uint32_t nd = (s + total + 3u) >> 2;
-	const uint32_t* s32 = (const uint32_t*)(slot + 12);       // s32[d+1] = staged bytes 4d .. 4d+3
-	for (uint32_t d = lane; d < nd; d += 64) {
-		const int t0 = (int)(4u * d) - (int)s;                 // staged byte held by the dword's first byte
-		if (t0 >= 0 && (uint32_t)t0 + 4u <= total) {
-			const uint32_t a = s32[d], b = s32[d + 1];
-			*(uint32_t*)(g0 + 4u * d) = s ? __builtin_amdgcn_alignbyte(b, a, 4u - s) : b;
-		} else {
-#pragma unroll
-			for (int q = 0; q < 4; q++) {
-				const int t = t0 + q;
-				if (t >= 0 && (uint32_t)t < total) g0[4u * d + q] = slot[16 + t];
-			}
-		}
-	}
-}
-
-// Tickets.  Flat form: one counter, tile-major over all GOPs (consecutive tickets = the same tile of different GOPs).
-// XCD form (ENC_XCD): every XCD has its own L2, and the table lines a tile needs follow its colours, so GOP g belongs
-// to XCD g % n_xcd and each XCD walks ITS GOPs in bands of ENC_BAND, tile-major inside a band: the workgroups that share
-// an L2 then work on a few neighbouring tiles of a few GOPs, whose table lines fit it, instead of on every GOP of the
-// clip at once.  A drained XCD steals from the next counter.  Either way a tile's predecessors (same GOP, lower tile)
-// carry older tickets of the same counter, so they are running or finished (forward progress of the look-back).
-// Returns tile * n_groups + group, or 0xffffffff when nothing is left.
-__device__ __forceinline__ uint32_t xcd_ticket_decode(const EncArgs& A, uint32_t k, uint32_t j)
-{
-	const uint32_t cnt = (A.n_groups - k + A.n_xcd - 1) / A.n_xcd;     // GOPs of XCD k (k < n_groups)
-	const uint32_t per_band = ENC_BAND * A.tpf;
-	const uint32_t b = j / per_band, r = j - b * per_band;
-	const uint32_t g0 = b * ENC_BAND, bsize = cnt - g0 < ENC_BAND ? cnt - g0 : ENC_BAND;
-	const uint32_t tile = r / bsize, lg = g0 + (r - tile * bsize);
-	return tile * A.n_groups + (k + lg * A.n_xcd);
-}
-
-__device__ __forceinline__ uint32_t draw_ticket(const EncArgs& A, uint32_t xcd, uint32_t first)
-{
-#if ENC_XCD
-	// `first` = ticket already drawn from the own counter
-	uint32_t k = xcd, j = first;
-	for (uint32_t tries = 0; tries < A.n_xcd; tries++) {
-		if (k < A.n_groups) {
-			const uint32_t cnt = (A.n_groups - k + A.n_xcd - 1) / A.n_xcd;
-			if (j < cnt * A.tpf) return xcd_ticket_decode(A, k, j);
-		}
-		k = k + 1 == A.n_xcd ? 0 : k + 1;
-		if (tries + 1 < A.n_xcd) j = atomicAdd(A.ctrl + 16 + k, 1u);
-	}
-	return 0xffffffffu;
-#else
-	return first;
-#endif
+	uint32_t head = s ? 4u - s : 0u;
+	if (head > total) head = total;
+	const uint32_t nbody = (total - head) >> 2, tail = (total - head) & 3u;
+	const uint8_t* sb = slot + 16 + head;
+	uint8_t* gb = gdst + head;
+	for (uint32_t d = lane; d < nbody; d += 64) *(uint32_t*)(gb + 4u * d) = *(const u32u*)(sb + 4u * d);
+	if ((uint32_t)lane < head) gdst[lane] = slot[16 + lane];
+	const uint32_t tl = (uint32_t)lane - 8u;
+	if (tl < tail) gb[4u * nbody + tl] = sb[4u * nbody + tl];
 }
 
 struct EncGeo {
@@ -782,14 +371,7 @@ __global__ __launch_bounds__(ENC_T, ENC_WPE) void k_encode(EncArgs A)
 	for (int i = tid; i < NROWS * MROW; i += ENC_T) s_mtx[i] = A.mtx[i];
 	for (int i = tid; i < C_END; i += ENC_T) s_ctl[i] = 0;
 	__syncthreads();
-#if ENC_XCD
-	const uint32_t xcd = (__builtin_amdgcn_s_getreg((3 << 11) | 20) & 15u) % A.n_xcd;   // HW_REG_XCC_ID[3:0]
-	uint32_t* const my_ctr = A.ctrl + 16 + xcd;
-#else
-	const uint32_t xcd = 0;
-	uint32_t* const my_ctr = A.ctrl;
-#endif
-	if (tid == 0) s_ctl[C_TICKET] = draw_ticket(A, xcd, atomicAdd(my_ctr, 1u));
+	if (tid == 0) s_ctl[C_TICKET] = atomicAdd(A.ctrl, 1u);
 	__syncthreads();                                           // the only workgroup barriers of the kernel
 
 	auto locate = [&](const EncGeo& g, uint32_t B, uint32_t& qx, uint32_t& qy) {   // block index (>= wb_c) -> block column / row
@@ -855,9 +437,9 @@ __global__ __launch_bounds__(ENC_T, ENC_WPE) void k_encode(EncArgs A)
 	uint32_t ip[8];                                            // the GOP's I-frame entries of this block, two u16 per register
 	uint4 px[4];
 	if (have) load_frame(g, A.pix + (size_t)f * npx, px);
-	bool have_prev = false, have_prev2 = false;                // items it-1 / it-2: tile, frame, bytes of this wave
-	uint32_t p_tile = 0, p_len = 0, p2_len = 0;
-	int p_f = 0, p2_f = 0;
+	bool have_prev = false;                                    // item it-1: tile, frame, bytes of this wave
+	uint32_t p_tile = 0, p_len = 0;
+	int p_f = 0;
 	uint32_t tk = 0;
 
 #ifdef ENC_PROF
@@ -900,23 +482,24 @@ __global__ __launch_bounds__(ENC_T, ENC_WPE) void k_encode(EncArgs A)
 				lds_st(gb + 1, it);
 			}
 		};
-		auto copy_out_prev2 = [&]() {                          // item it-2: its gbase was published during iteration it-1
-			if (!have_prev2 || p2_len == 0) return;
-			const uint32_t* gb = &s_ctl[C_GBASE + ((((it - 2) & (DF_SLOTS - 1))) * ENC_WAVES + wave) * 2];
-			lds_wait(gb + 1, it - 1, 0, A.ctrl, lane);
+		auto copy_out_prev = [&]() {
+#ifdef ABL_NOCOPYOUT
+			return;
+#endif
+			if (p_len == 0) return;
+			const uint32_t* gb = &s_ctl[C_GBASE + (pslot * ENC_WAVES + wave) * 2];
+			lds_wait(gb + 1, it, 0, A.ctrl, lane);
 			asm volatile("" ::: "memory");
 			const uint32_t base = __builtin_amdgcn_readfirstlane(lds_ld(gb));
-			wave_copy_own(s_stage0 + ((it & 1) * ENC_WAVES + wave) * WSLOT, A.out + (size_t)p2_f * A.out_stride + base, p2_len, lane);
+			wave_copy_own(s_stage0 + (((it - 1) & 1) * ENC_WAVES + wave) * WSLOT, A.out + (size_t)p_f * A.out_stride + base, p_len, lane);
 		};
 
-		if (!have) {                                           // drain: two more rounds for the last two items
-			if (!have_prev && !have_prev2) break;
-			copy_out_prev2();
-			if (duty) resolve_prev();
-			have_prev2 = have_prev; p2_f = p_f; p2_len = p_len;
-			have_prev = false;
-			it++;
-			continue;
+		if (!have) {                                           // final drain: item it-1 is the last one
+			if (have_prev) {
+				if (duty) resolve_prev();
+				copy_out_prev();
+			}
+			break;
 		}
 
 		PSTAMP(7);
@@ -934,7 +517,7 @@ __global__ __launch_bounds__(ENC_T, ENC_WPE) void k_encode(EncArgs A)
 #pragma unroll
 				for (int m = 0; m < 8; m++) ip[m] = 0;
 			}
-			if (wave == 0 && lane == 0) tk = atomicAdd(my_ctr, 1u);   // ticket of the NEXT tile, drawn a tile ahead
+			if (wave == 0 && lane == 0) tk = atomicAdd(A.ctrl, 1u);   // ticket of the NEXT tile, drawn a tile ahead
 		}
 		// ---- (Q) colour -> entry through the exact table, lane = (block, row)
 		uint32_t eq[16];
@@ -956,14 +539,13 @@ __global__ __launch_bounds__(ENC_T, ENC_WPE) void k_encode(EncArgs A)
 #endif
 		}
 		PSTAMP(0);
-		// ---- while the look-ups are in flight: next item's pixels, copy-out of item it-2, look-back of item it-1.
-		// The pixel loads are issued BEHIND the look-ups (the memory counter retires in order: ahead of them they would
-		// have to land before the first entry is usable).
+		// ---- next item's pixels, issued right BEHIND the look-ups (the memory counter retires in order: ahead of them
+		// they would have to land before the first entry is usable), and before the wait for the entries
 		asm volatile("" ::: "memory");
 		bool have_next = true;
 		if (new_tile && wave == 0) {                           // publish the next tile's ticket to the other waves
+			const uint32_t tkv = __builtin_amdgcn_readfirstlane(tk);
 			if (lane == 0) {
-				const uint32_t tkv = draw_ticket(A, xcd, tk);
 				uint32_t* tw = &s_ctl[C_TICKET + ((seq + 1) & (DF_SLOTS - 1)) * 2];
 				lds_st(tw, tkv);
 				asm volatile("" ::: "memory");
@@ -984,11 +566,6 @@ __global__ __launch_bounds__(ENC_T, ENC_WPE) void k_encode(EncArgs A)
 			}
 		}
 		PSTAMP(2);
-		copy_out_prev2();                                      // reads slot[it & 1] BEFORE this item's scratch / emission rewrite it
-		PSTAMP(6);
-		if (duty) resolve_prev();
-		PSTAMP(3);
-		asm volatile("" ::: "memory");
 		// [block][pixel] u16 table in the wave's scratch; a lane writes its row: 8 bytes at i*512 + lane*8
 #pragma unroll
 		for (int i = 0; i < 4; i++) {
@@ -998,6 +575,8 @@ __global__ __launch_bounds__(ENC_T, ENC_WPE) void k_encode(EncArgs A)
 			*(uint2*)(scratch + i * 512 + lane * 8) = q;
 		}
 		PSTAMP(1);
+		if (duty) resolve_prev();
+		PSTAMP(3);
 		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 		__builtin_amdgcn_wave_barrier();
 		// ---- transpose: lane = block reads its 16 entries (32 contiguous bytes), kept PACKED two per register
@@ -1069,7 +648,6 @@ __global__ __launch_bounds__(ENC_T, ENC_WPE) void k_encode(EncArgs A)
 		}
 		PSTAMP(4);
 		// ---- (E) emit this block's bytes into the wave's stage slot
-#if ENC_PKEMIT
 		// Codes are built two at a time in packed 16-bit lanes and written as {code, index} byte PAIRS at byte-granular
 		// LDS addresses (gfx950 runs DS in unaligned mode): when an entry has no escape byte its pair's second byte is
 		// overwritten by the next pair, and the one byte a block may spill past its end is the next block's flag --
@@ -1107,45 +685,11 @@ __global__ __launch_bounds__(ENC_T, ENC_WPE) void k_encode(EncArgs A)
 			asm volatile("" ::: "memory");
 			sp[0] = copy ? COPY_FLAG : (fill ? FILL_FLAG : NORMAL_FLAG);
 		}
-#else
-		if (g.valid) {
-			uint8_t* sp = wslot + 16 + incl - len;
-			if (copy) {
-				sp[0] = COPY_FLAG;
-			} else if (fill) {
-				sp[0] = FILL_FLAG;
-				if (M512) {
-					const uint32_t idx = e0 & 0xffu, p7 = (e0 >> 1) & 0x80u;
-					sp[1] = (uint8_t)(p7 | (idx < 127u ? idx : 127u));        // :382-388
-					if (idx >= 127u) sp[2] = (uint8_t)idx;
-				} else {
-					sp[1] = (uint8_t)e0;                                       // :421
-				}
-			} else {
-				sp[0] = NORMAL_FLAG;
-				uint32_t pos = 1;
-#pragma unroll
-				for (int m = 0; m < 8; m++) {
-#pragma unroll
-					for (int hf = 0; hf < 2; hf++) {
-						const uint32_t ek = hf ? ep[m] >> 16 : ep[m] & 0xffffu;
-						if (M512) {
-							const uint32_t idx = ek & 0xffu, p7 = (ek >> 1) & 0x80u;
-							sp[pos] = (uint8_t)(p7 | (idx < 127u ? idx : 127u));    // :395-401
-							if (idx >= 127u) sp[pos + 1] = (uint8_t)idx;
-							pos += 1u + (idx >= 127u ? 1u : 0u);
-						} else {
-							sp[pos++] = (uint8_t)ek;                               // :428-429
-						}
-					}
-				}
-			}
-		}
-#endif
 		PSTAMP(5);
+		if (have_prev) copy_out_prev();
+		PSTAMP(6);
 
 		// ---- next item
-		have_prev2 = have_prev; p2_f = p_f; p2_len = p_len;
 		have_prev = true; p_tile = g.tile; p_f = f; p_len = wtot;
 		it++;
 		if (f + 1 < g.f_hi) {
@@ -1161,7 +705,6 @@ __global__ __launch_bounds__(ENC_T, ENC_WPE) void k_encode(EncArgs A)
 		for (int k = 0; k < 8; k++) atomicAdd(A.ctrl + 32 + k, prof[k] >> 10);
 #endif
 }
-#endif
 
 // ----------------------------------------------------------------------------------------------
 // decode side
@@ -2194,8 +1737,6 @@ extern "C" int agmv_hip_encode_frames_dev(agmv_hip_ctx* c, const uint32_t* d_pix
 	A.first_fc = first_fc; A.phase = first_fc & 3u;
 	A.n_groups = (n_frames + A.phase + 3) / 4;
 	A.total_tiles = A.n_groups * A.tpf;
-	A.n_xcd = c->n_cu >= 64 ? (uint32_t)c->n_cu / 32u : 1u;      // MI355X: 256 CUs in 8 XCDs
-	if (A.n_xcd > 16) A.n_xcd = 16;
 	if (A.phase != 0 && !d_ientries) {
 		snprintf(g_err, sizeof(g_err), "agmv_hip: batch starts inside a GOP (frame_count %u) but no I-frame entries were supplied", first_fc);
 		return -1;
@@ -2215,11 +1756,7 @@ extern "C" int agmv_hip_encode_frames_dev(agmv_hip_ctx* c, const uint32_t* d_pix
 	CK(hipMemsetAsync(c->d_ctrl, 0, CTRL_BYTES, s));
 	uint32_t grid = (uint32_t)c->enc_grid;
 	if (grid > A.total_tiles) grid = A.total_tiles;
-#if ENC_DF
 	const size_t lds = (size_t)(c->mode512 ? 512 : 256) * MROW * 4 + ENC_LDS_EXTRA;
-#else
-	const size_t lds = (size_t)(c->mode512 ? 512 : 256) * MROW * 4 + 2 * STAGE_SZ + 128;
-#endif
 	if (c->mode512) CK(hipFuncSetAttribute((const void*)k_encode<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
 	else CK(hipFuncSetAttribute((const void*)k_encode<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
 	ev_mark(c, 0, s);

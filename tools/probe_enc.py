@@ -13,6 +13,11 @@ frames = hip.synth_dev(W, H, 0, T)
 kind = sys.argv[1] if len(sys.argv) > 1 else "synth"
 if kind == "noise":
     frames = torch.randint(0, 1 << 24, (T, H, W), dtype=torch.int32, device="cuda")
+elif kind == "flat":     # one colour everywhere: every look-up of a wave hits the same table line
+    frames = torch.full((T, H, W), 0x336699, dtype=torch.int32, device="cuda")
+elif kind == "hgrad":    # colour depends on x only, slowly: a 64-pixel span stays inside one or two 4x4x4 cubes
+    x = (torch.arange(W, device="cuda", dtype=torch.int32) // 16) & 0xff
+    frames = (x | (x << 8) | (x << 16)).view(1, 1, W).expand(T, H, W).contiguous()
 elif kind == "noise3":   # synthetic with every pixel's low 3 bits randomised -> NORMAL blocks, local LUT access
     frames = frames ^ torch.randint(0, 8, (T, H, W), dtype=torch.int32, device="cuda") ^ (torch.randint(0, 8, (T, H, W), dtype=torch.int32, device="cuda") << 8) ^ (torch.randint(0, 8, (T, H, W), dtype=torch.int32, device="cuda") << 16)
 out = torch.empty((T, hip.max_usize(W, H)), dtype=torch.uint8, device="cuda")
