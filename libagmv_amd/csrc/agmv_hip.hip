@@ -61,6 +61,7 @@ extern "C" const char* agmv_hip_last_error(void) { return g_err; }
 #endif
 constexpr int ENC_T = ENC_T_OVERRIDE;          // threads per encode workgroup = 4x4 blocks per tile
 constexpr int ENC_WAVES = ENC_T / 64;
+static_assert(ENC_WAVES >= 1 && ENC_WAVES <= 16, "the per-wave offsets are scanned inside one 16-lane row");
 constexpr int MROW = 17;            // dwords per matrix row: 16 used + 1 pad (LDS bank spread)
 #ifndef DEC_T_OVERRIDE
 #define DEC_T_OVERRIDE 256
@@ -216,21 +217,28 @@ __device__ __forceinline__ void lds_barrier()
 #endif
 }
 
-__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t x, int lane)
+// Wave-wide scans on the VALU's DPP lanes (row shifts inside the 16-lane rows, then the two row broadcasts gfx9 has
+// for exactly this) -- six dependent adds, no LDS round trips (__shfl_up compiles to ds_bpermute + a wait per step).
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t dpp_or0(uint32_t x)       // lanes without a source (or masked off) read 0
 {
-#pragma unroll
-	for (int d = 1; d < 64; d <<= 1) {
-		uint32_t y = __shfl_up(x, d, 64);
-		if (lane >= d) x += y;
-	}
+	return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, CTRL, ROW_MASK, 0xF, false);
+}
+
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t x, int)
+{
+	x += dpp_or0<0x111, 0xF>(x);                               // row_shr:1
+	x += dpp_or0<0x112, 0xF>(x);                               // row_shr:2
+	x += dpp_or0<0x114, 0xF>(x);                               // row_shr:4
+	x += dpp_or0<0x118, 0xF>(x);                               // row_shr:8
+	x += dpp_or0<0x142, 0xA>(x);                               // row_bcast:15 -> rows 1 and 3
+	x += dpp_or0<0x143, 0xC>(x);                               // row_bcast:31 -> rows 2 and 3
 	return x;
 }
 
-__device__ __forceinline__ uint32_t wave_sum(uint32_t x)
+__device__ __forceinline__ uint32_t wave_sum(uint32_t x)      // the same value in every lane
 {
-#pragma unroll
-	for (int d = 32; d >= 1; d >>= 1) x += __shfl_xor(x, d, 64);
-	return x;
+	return (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_scan(x, 0), 63);
 }
 
 // decoupled look-back over the tiles of one frame (run by ONE wave; returns the exclusive
@@ -470,11 +478,10 @@ __global__ __launch_bounds__(ENC_T, ENC_WPE) void k_encode(EncArgs A)
 			// every wave of the tile has published its byte count (the tile total exists): exclusive scan over the waves
 			const uint32_t ws = lane < ENC_WAVES ? (lds_ld(&s_ctl[C_WSUM + pslot * ENC_WAVES + lane]) & 0xffffu) : 0u;
 			uint32_t inc = ws;
-#pragma unroll
-			for (int d = 1; d < ENC_WAVES; d <<= 1) {
-				const uint32_t y = __shfl_up(inc, d, 64);
-				if (lane >= d) inc += y;
-			}
+			inc += dpp_or0<0x111, 0xF>(inc);                    // the waves sit in the first lanes of row 0
+			if (ENC_WAVES > 2) inc += dpp_or0<0x112, 0xF>(inc);
+			if (ENC_WAVES > 4) inc += dpp_or0<0x114, 0xF>(inc);
+			if (ENC_WAVES > 8) inc += dpp_or0<0x118, 0xF>(inc);
 			if (lane < ENC_WAVES) {
 				uint32_t* gb = &s_ctl[C_GBASE + (pslot * ENC_WAVES + lane) * 2];
 				lds_st(gb, excl + inc - ws);

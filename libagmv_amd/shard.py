@@ -6,6 +6,14 @@ decoding.  One process per GPU; the only collective is the FINAL GATHER of the p
 the rank that runs the host LZ stage and writes the container in frame order (RCCL over xGMI with the
 "nccl" backend, gloo in the CPU tests).  Each peer sends over its own direct link to the root, so this is
 a plain gather (sizes first, then the variable-length payloads), not a ring.
+
+Decode shards the same way.  A GOP is self-contained for every stream the encoder can emit; only a stream that
+raises the reference's `escape` (blocks the bitstream does not reach keep the previous frame's pixels, reference
+src/agmv_decode.c:229-232) or carries a COPY block in an I-frame (reads the snapshot of the previous GOP, :277-285)
+makes a range depend on the decoder state before it.  decode_sharded() decodes every range in parallel from the fresh
+state, finds the dependent ranges from the parser's own outputs, and repairs exactly those with a serial hand-off of
+(last frame, last I-frame snapshot) from the rank before -- a point-to-point send per dependent boundary, nothing
+otherwise.
 """
 import torch
 
@@ -73,3 +81,91 @@ def split_packed(sizes, packed):
         out.append(packed[off:off + int(s)])
         off += int(s)
     return out
+
+
+COPY_FLAG = 0x5E            # include/agmv_defines.h:51
+NORMAL_FLAG = 0x2F          # :50
+
+
+def range_depends_on_prior_state(bits, bpos, offsets, nentered, nblk, mode512=True, first_is_iframe=True):
+    """True when the pixels of a range may depend on img_data / iframe_data from before its first frame.
+    bits [n, stride] uint8, bpos [n], offsets [n, nblk] (byte position at which each block is entered), nentered [n].
+      (a) a frame that raises `escape` leaves blocks >= nentered at the previous frame's values;
+      (b) a COPY block in the range's first frame reads the snapshot taken before the range;
+      (c) a NORMAL block that runs past bpos stops writing pixels (per-pixel over-run check, :310-314 / :386-392);
+          followed by another block that is case (a), as the LAST block of a frame it has to be looked at itself.
+    Everything else a frame writes is a function of its own bitstream and of frames inside the range."""
+    n = int(nentered.numel())
+    if n == 0:
+        return False
+    if bool((nentered < nblk).any()):
+        return True
+    if not first_is_iframe:
+        return True                                           # the range continues a GOP of the caller's
+    flags = bits[0].gather(0, offsets[0].to(torch.int64))
+    if bool((flags == COPY_FLAG).any()):
+        return True
+    # (c): length of every frame's last block (<= 33 bytes), walked on the host for all frames at once
+    start = offsets[:, nblk - 1].to(torch.int64)
+    idx = (start[:, None] + torch.arange(34, device=bits.device)[None, :]).clamp_(max=bits.shape[1] - 1)
+    win = bits.gather(1, idx).cpu().numpy()
+    end = start.cpu().numpy().copy()
+    for f in range(n):
+        w = win[f]
+        if w[0] != NORMAL_FLAG:
+            continue                                          # FILL / COPY write all 16 pixels whatever they read
+        pos = 1
+        for _ in range(16):
+            pos += 2 if (mode512 and (w[pos] & 0x7f) == 127) else 1
+        end[f] += pos
+    return bool((end > bpos.cpu().numpy().astype(end.dtype)).any())
+
+
+def decode_sharded(dist, decode_range, n_frames, first_frame_count=0, prev=None, prev_iframe=None):
+    """Bit-exact GOP-sharded decode.  decode_range(lo, hi, prev, prev_iframe) decodes frames [lo, hi) of the clip from
+    the given prior state (None = fresh decoder) and returns (pixels [hi-lo, H, W] int32, depends: bool) where
+    `depends` is range_depends_on_prior_state() of that range.  Returns this rank's (lo, hi, pixels).
+    Hand-off: after the parallel pass the `depends` flags are all-gathered; for each dependent rank r (in rank order)
+    the nearest non-empty rank before it sends its final frame and its I-frame snapshot, and r decodes again."""
+    world, rank = dist.get_world_size(), dist.get_rank()
+    ranges = gop_ranges(n_frames, world, first_frame_count)
+    lo, hi = ranges[rank]
+    pix, dep = decode_range(lo, hi, prev if rank == 0 else None, prev_iframe if rank == 0 else None)
+    dev = pix.device
+    flag = torch.tensor([1 if (dep and rank > 0) else 0], dtype=torch.int64, device=dev)
+    flags = [torch.empty_like(flag) for _ in range(world)]
+    dist.all_gather(flags, flag)
+    need = [bool(int(f.item())) for f in flags]
+
+    def last_state(p, r_lo, r_hi, in_prev, in_iframe):
+        """(img_data, iframe_data) after the last frame of a decoded non-empty range"""
+        last = p[-1]
+        snap = in_iframe
+        for f in range(r_hi - 1, r_lo - 1, -1):               # D4: snapshot at frame_count % 4 == 0 (:401-405)
+            if ((first_frame_count + f) & 3) == 0:
+                snap = p[f - r_lo]
+                break
+        return last, snap
+
+    # the state entering this rank, once known to be needed
+    in_prev, in_iframe = (prev, prev_iframe) if rank == 0 else (None, None)
+    for r in range(1, world):
+        if not need[r] or ranges[r][1] <= ranges[r][0]:
+            continue
+        src = max((q for q in range(r) if ranges[q][1] > ranges[q][0]), default=None)
+        if src is None:
+            continue                                          # nothing before it: the caller's state is rank 0's
+        if rank == src:
+            last, snap = last_state(pix, lo, hi, in_prev, in_iframe)
+            if snap is None:
+                snap = torch.zeros_like(last)                  # fresh decoder: zeroed iframe (:532-560)
+            dist.send(last.contiguous(), dst=r)
+            dist.send(snap.contiguous(), dst=r)
+        elif rank == r:
+            shape = pix.shape[1:]
+            in_prev = torch.empty(shape, dtype=pix.dtype, device=dev)
+            in_iframe = torch.empty(shape, dtype=pix.dtype, device=dev)
+            dist.recv(in_prev, src=src)
+            dist.recv(in_iframe, src=src)
+            pix, _ = decode_range(lo, hi, in_prev, in_iframe)
+    return lo, hi, pix
