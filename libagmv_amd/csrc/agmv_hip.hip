@@ -56,6 +56,9 @@ extern "C" const char* agmv_hip_last_error(void) { return g_err; }
 #ifndef ENC_WPE
 #define ENC_WPE 4
 #endif
+#ifndef ENC_PRIO
+#define ENC_PRIO 2          /* s_setprio while a wave issues its look-ups + pixel loads (0 = off): the memory pipeline is the scarce unit */
+#endif
 #ifndef ENC_PIXAUX
 #define ENC_PIXAUX 2          /* cache policy of the pixel loads: 2 = nt (streamed once; keeps L2 for the table), 0 = default */
 #endif
@@ -498,6 +501,7 @@ __global__ __launch_bounds__(ENC_T, ENC_WPE) void k_encode(EncArgs A)
 			lds_wait(gb + 1, it, 0, A.ctrl, lane);
 			asm volatile("" ::: "memory");
 			const uint32_t base = __builtin_amdgcn_readfirstlane(lds_ld(gb));
+			PSTAMP(6);
 			wave_copy_own(s_stage0 + (((it - 1) & 1) * ENC_WAVES + wave) * WSLOT, A.out + (size_t)p_f * A.out_stride + base, p_len, lane);
 		};
 
@@ -509,7 +513,6 @@ __global__ __launch_bounds__(ENC_T, ENC_WPE) void k_encode(EncArgs A)
 			break;
 		}
 
-		PSTAMP(7);
 		const bool is_i = ((A.first_fc + f) & 3u) == 0;
 		uint8_t* wslot = s_stage0 + ((it & 1) * ENC_WAVES + wave) * WSLOT;   // free since this wave's copy-out of item it-2
 		uint8_t* scratch = wslot + 16;
@@ -526,6 +529,9 @@ __global__ __launch_bounds__(ENC_T, ENC_WPE) void k_encode(EncArgs A)
 			}
 			if (wave == 0 && lane == 0) tk = atomicAdd(A.ctrl, 1u);   // ticket of the NEXT tile, drawn a tile ahead
 		}
+#if ENC_PRIO
+		__builtin_amdgcn_s_setprio(ENC_PRIO);
+#endif
 		// ---- (Q) colour -> entry through the exact table, lane = (block, row)
 		uint32_t eq[16];
 #ifdef ABL_SMALLLUT
@@ -572,6 +578,9 @@ __global__ __launch_bounds__(ENC_T, ENC_WPE) void k_encode(EncArgs A)
 				load_frame(gn, A.pix + (size_t)gn.f_lo * npx, px);
 			}
 		}
+#if ENC_PRIO
+		__builtin_amdgcn_s_setprio(0);
+#endif
 		PSTAMP(2);
 		// [block][pixel] u16 table in the wave's scratch; a lane writes its row: 8 bytes at i*512 + lane*8
 #pragma unroll
@@ -694,7 +703,7 @@ __global__ __launch_bounds__(ENC_T, ENC_WPE) void k_encode(EncArgs A)
 		}
 		PSTAMP(5);
 		if (have_prev) copy_out_prev();
-		PSTAMP(6);
+		PSTAMP(7);
 
 		// ---- next item
 		have_prev = true; p_tile = g.tile; p_f = f; p_len = wtot;
@@ -1786,7 +1795,7 @@ extern "C" int agmv_hip_check(agmv_hip_ctx* c, void* stream)
 		CK(hipMemcpy(pr, c->d_ctrl + 32, 32, hipMemcpyDeviceToHost));
 		double tot = 0;
 		for (int k = 0; k < 8; k++) tot += pr[k];
-		fprintf(stderr, "k_encode phases (%% of wave time): issue %.1f | look-up wait+stores %.1f | prefetch+ticket %.1f | duty %.1f | classify+scan %.1f | emit %.1f | copy-out %.1f | loop top %.1f\n",
+		fprintf(stderr, "k_encode phases (%% of wave time): loop top + look-up issue %.1f | look-up wait + park %.1f | prefetch+ticket %.1f | duty %.1f | classify+scan %.1f | emit %.1f | wait for gbase %.1f | copy-out %.1f\n",
 		        100 * pr[0] / tot, 100 * pr[1] / tot, 100 * pr[2] / tot, 100 * pr[3] / tot, 100 * pr[4] / tot, 100 * pr[5] / tot, 100 * pr[6] / tot, 100 * pr[7] / tot);
 	}
 #endif
