@@ -540,3 +540,49 @@ def test_full_size_properties(torch, hip):
         exp = enc.encode(f_np[t])
         got = out1[t, :sz[t]].cpu().numpy()
         assert len(got) == len(exp) and (got == exp).all()
+
+
+@pytest.mark.parametrize("kind", ["clean", "escape", "copy", "overrun"])
+def test_gop_range_decode_and_dependency_predicate(torch, hip, kind):
+    """what libagmv_amd.shard.decode_sharded relies on, with the real parser and k_decode: a GOP range decoded on its
+    own (fresh decoder state) equals the serial decode unless shard.range_depends_on_prior_state says it depends on
+    earlier frames -- and then it does once the hand-off state (last frame, I-frame snapshot) is supplied."""
+    from libagmv_amd import shard
+    W, H, T, cut = 64, 48, 16, 8
+    nblk = W * H // 16
+    frames = np.stack([S.synth_frame(W, H, t) for t in range(T)])
+    p0, p1 = S.content_palettes(frames[:4])
+    hip.set_palette(p0, p1, True)
+    bits = [b.copy() for b in gpu_encode(torch, hip, frames)]
+    if kind == "escape":
+        for f in (7, 8, 11):
+            bits[f] = bits[f][:len(bits[f]) * 5 // 8]
+    elif kind == "copy":
+        bits[8] = np.full(nblk, 0x5E, np.uint8)
+    elif kind == "overrun":                                    # the range's first frame: FILL blocks, then a last NORMAL block the stream ends inside
+        bits[8] = np.concatenate([np.tile(np.array([0x4E, 7], np.uint8), nblk - 1), np.array([0x2F, 1, 2, 3, 4, 5], np.uint8)])
+    dec = O.OracleDecoder(W, H, True, p0, p1)
+    exp, pads = [], []
+    for b in bits:
+        pix, padded, _, _ = dec.decode(b, want_tables=True)
+        exp.append(pix)
+        pads.append(padded[len(b):len(b) + 16])
+    # second range on its own
+    stride = (max(len(b) for b in bits) + 16 + 255) & ~255
+    slab = np.zeros((T - cut, stride), np.uint8)
+    for i, f in enumerate(range(cut, T)):
+        slab[i, :len(bits[f])] = bits[f]
+        slab[i, len(bits[f]):len(bits[f]) + 16] = pads[f]
+    alone, offs, nent = gpu_decode(torch, hip, bits[cut:], pads[cut:], W, H, first_fc=cut)
+    dep = shard.range_depends_on_prior_state(torch.from_numpy(slab), torch.tensor([len(b) for b in bits[cut:]], dtype=torch.int32),
+                                             torch.from_numpy(offs.astype(np.int64)), torch.from_numpy(nent.astype(np.int32)), nblk, True)
+    same = all((alone[i] == exp[cut + i]).all() for i in range(T - cut))
+    assert dep == (kind != "clean")
+    if not dep:
+        assert same
+    else:
+        assert not same, "the damaged clip was meant to make the range depend on earlier frames"
+        first, _, _ = gpu_decode(torch, hip, bits[:cut], pads[:cut], W, H)
+        fixed, _, _ = gpu_decode(torch, hip, bits[cut:], pads[cut:], W, H, first_fc=cut, prev=first[cut - 1], prev_iframe=first[cut - 4])
+        for i in range(T - cut):
+            assert (fixed[i] == exp[cut + i]).all(), "frame %d after the hand-off" % (cut + i)
