@@ -94,6 +94,8 @@ struct agmv_hip_ctx {
 	unsigned long long* d_status;   // look-back words
 	size_t status_cap;              // in words
 	uint32_t* d_ctrl;               // [0] ticket, [1] error, padded to 16 B
+	uint16_t* d_ient_tmp;           // encode: I-frame entries written by a batch that also READS the caller's plane
+	size_t ient_cap;                // in entries
 	uint32_t* d_dirty;              // decode: bitmap of block positions needing the fix-up
 	size_t dirty_cap;               // in words
 	int enc_grid;                   // resident workgroups for the persistent encode kernel
@@ -204,7 +206,8 @@ struct EncArgs {
 	const uint32_t* mtx;
 	unsigned long long* status;
 	uint32_t* ctrl;
-	uint16_t* ientries;
+	const uint16_t* ientries_in;    // entries of the GOP's I-frame when the batch starts inside a GOP
+	uint16_t* ientries_out;         // receives the entries of the batch's last I-frame (never the buffer read above)
 	unsigned long long out_stride;
 	uint32_t n_frames, w, h, bw, nblk, tpf, first_fc, phase, n_groups, last_iframe, total_tiles;
 };
@@ -496,10 +499,13 @@ __global__ __launch_bounds__(ENC_T, ENC_WPE) void k_encode(EncArgs A)
 #ifdef ABL_NOCOPYOUT
 			return;
 #endif
-			if (p_len == 0) return;
+			// EVERY wave waits here, also one with nothing to copy: this wait is what bounds the drift between the waves
+			// (see the header comment) -- a wave of blocks past the end of the frame must not run rounds ahead and recycle
+			// control slots the others still read
 			const uint32_t* gb = &s_ctl[C_GBASE + (pslot * ENC_WAVES + wave) * 2];
 			lds_wait(gb + 1, it, 0, A.ctrl, lane);
 			asm volatile("" ::: "memory");
+			if (p_len == 0) return;
 			const uint32_t base = __builtin_amdgcn_readfirstlane(lds_ld(gb));
 			PSTAMP(6);
 			wave_copy_own(s_stage0 + (((it - 1) & 1) * ENC_WAVES + wave) * WSLOT, A.out + (size_t)p_f * A.out_stride + base, p_len, lane);
@@ -520,7 +526,7 @@ __global__ __launch_bounds__(ENC_T, ENC_WPE) void k_encode(EncArgs A)
 			if (((A.first_fc + g.f_lo) & 3u) != 0) {           // GOP started in an earlier batch
 #pragma unroll
 				for (int r = 0; r < 4; r++) {
-					const uint2 q = *(const uint2*)(A.ientries + g.poff + r * A.w);
+					const uint2 q = *(const uint2*)(A.ientries_in + g.poff + r * A.w);
 					ip[2 * r] = q.x; ip[2 * r + 1] = q.y;
 				}
 			} else {
@@ -632,12 +638,12 @@ __global__ __launch_bounds__(ENC_T, ENC_WPE) void k_encode(EncArgs A)
 		if (is_i) {                                            // iframe_entries = img_entry, :626-630
 #pragma unroll
 			for (int m = 0; m < 8; m++) ip[m] = ep[m];
-			if (A.ientries && (uint32_t)f == A.last_iframe && g.valid) {
+			if (A.ientries_out && (uint32_t)f == A.last_iframe && g.valid) {
 #pragma unroll
 				for (int r = 0; r < 4; r++) {
 					uint2 q;
 					q.x = ep[2 * r]; q.y = ep[2 * r + 1];
-					*(uint2*)(A.ientries + g.poff + r * A.w) = q;
+					*(uint2*)(A.ientries_out + g.poff + r * A.w) = q;
 				}
 			}
 		}
@@ -1654,7 +1660,7 @@ extern "C" void agmv_hip_destroy(agmv_hip_ctx* c)
 	if (!c) return;
 	(void)hipSetDevice(c->device);
 	(void)hipFree(c->d_lut); (void)hipFree(c->d_mtx); (void)hipFree(c->d_pal); (void)hipFree(c->d_ctrl);
-	(void)hipFree(c->d_status); (void)hipFree(c->d_dirty); (void)hipFree(c->d_parse_ws);
+	(void)hipFree(c->d_status); (void)hipFree(c->d_dirty); (void)hipFree(c->d_parse_ws); (void)hipFree(c->d_ient_tmp);
 	free(c);
 }
 
@@ -1746,7 +1752,7 @@ extern "C" int agmv_hip_encode_frames_dev(agmv_hip_ctx* c, const uint32_t* d_pix
 	hipStream_t s = (hipStream_t)stream;
 	EncArgs A;
 	memset(&A, 0, sizeof(A));
-	A.pix = d_pix; A.out = d_out; A.sizes = d_sizes; A.lut = c->d_lut; A.mtx = c->d_mtx; A.ientries = d_ientries;
+	A.pix = d_pix; A.out = d_out; A.sizes = d_sizes; A.lut = c->d_lut; A.mtx = c->d_mtx; A.ientries_in = d_ientries; A.ientries_out = d_ientries;
 	A.out_stride = out_stride;
 	A.n_frames = n_frames; A.w = w; A.h = h; A.bw = w / 4; A.nblk = (w / 4) * (h / 4);
 	A.tpf = (A.nblk + ENC_T - 1) / ENC_T;
@@ -1768,6 +1774,20 @@ extern "C" int agmv_hip_encode_frames_dev(agmv_hip_ctx* c, const uint32_t* d_pix
 		c->status_cap = need;
 	}
 	A.status = c->d_status; A.ctrl = c->d_ctrl;
+	// A batch that starts inside a GOP READS the caller's entry plane (its first tiles) and, if it also holds an I-frame,
+	// WRITES the plane (other tiles of the same positions, running at the same time): the new entries go to a scratch
+	// plane and are copied over the caller's when the kernel is done.
+	const bool ient_both = d_ientries && A.phase != 0 && A.last_iframe != 0xffffffffu;
+	const size_t npx_e = (size_t)w * h;
+	if (ient_both) {
+		if (npx_e > c->ient_cap) {
+			if (c->d_ient_tmp) CK(hipFree(c->d_ient_tmp));
+			c->d_ient_tmp = nullptr; c->ient_cap = 0;
+			CK(hipMalloc(&c->d_ient_tmp, npx_e * sizeof(uint16_t)));
+			c->ient_cap = npx_e;
+		}
+		A.ientries_out = c->d_ient_tmp;
+	}
 	CK(hipMemsetAsync(c->d_status, 0, need * sizeof(unsigned long long), s));
 	CK(hipMemsetAsync(c->d_ctrl, 0, CTRL_BYTES, s));
 	uint32_t grid = (uint32_t)c->enc_grid;
@@ -1780,6 +1800,7 @@ extern "C" int agmv_hip_encode_frames_dev(agmv_hip_ctx* c, const uint32_t* d_pix
 	else hipLaunchKernelGGL(k_encode<false>, dim3(grid), dim3(ENC_T), lds, s, A);
 	ev_mark(c, 1, s);
 	CK(hipGetLastError());
+	if (ient_both) CK(hipMemcpyAsync(d_ientries, c->d_ient_tmp, npx_e * sizeof(uint16_t), hipMemcpyDeviceToDevice, s));
 	return 0;
 }
 

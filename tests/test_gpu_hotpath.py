@@ -586,3 +586,24 @@ def test_gop_range_decode_and_dependency_predicate(torch, hip, kind):
         fixed, _, _ = gpu_decode(torch, hip, bits[cut:], pads[cut:], W, H, first_fc=cut, prev=first[cut - 1], prev_iframe=first[cut - 4])
         for i in range(T - cut):
             assert (fixed[i] == exp[cut + i]).all(), "frame %d after the hand-off" % (cut + i)
+
+
+def test_encode_batch_reads_and_writes_entry_plane(torch, hip):
+    """a batch that starts inside a GOP reads the caller's I-frame entry plane while tiles of its own next I-frame
+    produce the new one (fuzz seed 361 caught the two meeting in one buffer): P-frames that equal the NEXT I-frame turn
+    into COPY blocks if they see its entries.  Repeated, since the overlap is a matter of timing."""
+    W, H = 320, 72
+    rng = np.random.default_rng(5)
+    blocks = lambda: np.repeat(np.repeat(rng.integers(0, 1 << 24, size=(H // 8, W // 8), dtype=np.uint32), 8, 0), 8, 1)
+    a, b = S.synth_frame(W, H, 3), blocks()
+    frames = np.stack([a, blocks(), b, b, b, b, b, b, b])     # frames 2..3 equal the I-frames 4 and 8 that follow them
+    p0, p1 = S.content_palettes(frames[:4])
+    for mode512 in (False, True):
+        hip.set_palette(p0, p1, mode512)
+        whole = gpu_encode(torch, hip, frames)
+        for rep in range(25):
+            ient = torch.zeros(W * H, dtype=torch.int16, device="cuda")
+            first = gpu_encode(torch, hip, frames[:1], first_fc=0, ientries=ient)
+            rest = gpu_encode(torch, hip, frames[1:], first_fc=1, ientries=ient)
+            for t, got in enumerate(first + rest):
+                assert len(got) == len(whole[t]) and (got == whole[t]).all(), "rep %d frame %d mode512=%s" % (rep, t, mode512)
