@@ -335,7 +335,7 @@ __device__ __forceinline__ uint32_t lds_wait(const uint32_t* p, uint32_t tag, in
 	unsigned spins = 0;
 	while ((v >> shift) != tag) {
 		__builtin_amdgcn_s_sleep(1);
-		if (++spins > (1u << 18)) {
+		if (++spins > (1u << 20)) {                          // ~0.1 s; a legitimate wait is microseconds
 			if (lane == 0) atomicExch(ctrl + 1, 2u);
 			break;
 		}
