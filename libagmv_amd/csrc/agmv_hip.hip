@@ -130,6 +130,22 @@ __host__ __device__ __forceinline__ uint32_t lut_index(uint32_t px)
 #endif
 }
 
+// byte offset of a colour's entry, = 2 * lut_index(px), in 5 VALU for the sparse form (and, mul, bfe, and, lshl_or):
+// bit 15 of the product is always 0, so the 7-bit field at bit 15 is the in-cube index already doubled
+__device__ __forceinline__ uint32_t lut_offset(uint32_t px)
+{
+#if LUT_SPARSE
+	const uint32_t m = __umul24(px & 0x030303u, 0x10410u);       // full-rate 24-bit multiply (a 32-bit v_mul_lo is quarter rate)
+	const uint32_t hi = px & 0xFCFCFCu;
+	uint32_t lo, off;                                          // spelled out: the compiler turns this into 4 instructions otherwise
+	asm("v_bfe_u32 %0, %1, 15, 7" : "=v"(lo) : "v"(m));
+	asm("v_lshl_or_b32 %0, %1, 5, %2" : "=v"(off) : "v"(hi), "v"(lo));
+	return off;
+#else
+	return lut_index(px) * 2u;
+#endif
+}
+
 // ----------------------------------------------------------------------------------------------
 // K0: exact colour -> entry table.  One thread per colour; the palette index is wave-uniform so
 // the palette is read through the scalar cache.  Same argmin + tie rules as the reference:
@@ -541,9 +557,9 @@ __global__ __launch_bounds__(ENC_T, ENC_WPE) void k_encode(EncArgs A)
 		// ---- (Q) colour -> entry through the exact table, lane = (block, row)
 		uint32_t eq[16];
 #ifdef ABL_SMALLLUT
-#define LUT_OFF(c) ((lut_index(c) * 2u) & 0x1FFFFEu)
+#define LUT_OFF(c) (lut_offset(c) & 0x1FFFFEu)
 #else
-#define LUT_OFF(c) (lut_index(c) * 2u)
+#define LUT_OFF(c) lut_offset(c)
 #endif
 #pragma unroll
 		for (int i = 0; i < 4; i++) {
