@@ -377,6 +377,28 @@ __device__ __forceinline__ void wave_copy_own(const uint8_t* slot, uint8_t* gdst
 	if (tl < tail) gb[4u * nbody + tl] = sb[4u * nbody + tl];
 }
 
+// The two block tests of one 4x4 block (entries packed two per register): acc1 collects one matrix bit per pixel
+// against the block's top-left entry (row0), acc2 -- P-frames only -- against the I-frame's entry of the same pixel.
+template <bool M512, bool PFRAME>
+__device__ __forceinline__ void block_tests(const uint32_t (&ep)[8], const uint32_t (&ip)[8], const uint32_t* s_mtx,
+                                            uint32_t row0, uint32_t& acc1, uint32_t& acc2, uint32_t& nesc)
+{
+#pragma unroll
+	for (int m = 0; m < 8; m++) {
+		const uint32_t p = ep[m], a5 = (p >> 5) & 0x7ffu, b5 = p >> 21, bh = p >> 16;
+		const uint32_t wa = s_mtx[row0 + a5], wb = s_mtx[row0 + b5];
+		acc1 = __builtin_amdgcn_alignbit(wa >> (p & 31u), acc1, 1);
+		acc1 = __builtin_amdgcn_alignbit(wb >> (bh & 31u), acc1, 1);
+		if (M512) nesc += ((p & 0xffu) >= 127u ? 1u : 0u) + ((bh & 0xffu) >= 127u ? 1u : 0u);
+		if (PFRAME) {
+			const uint32_t q = ip[m];
+			const uint32_t va = s_mtx[(q & 0xffffu) * MROW + a5], vb = s_mtx[(q >> 16) * MROW + b5];
+			acc2 = __builtin_amdgcn_alignbit(va >> (p & 31u), acc2, 1);
+			acc2 = __builtin_amdgcn_alignbit(vb >> (bh & 31u), acc2, 1);
+		}
+	}
+}
+
 struct EncGeo {
 	uint32_t tile, wbase, wb_c, wbx, wby;                      // wave-uniform
 	int f_lo, f_hi, path;
@@ -628,20 +650,10 @@ __global__ __launch_bounds__(ENC_T, ENC_WPE) void k_encode(EncArgs A)
 		// (src/agmv_encode.c:240-300); one matrix bit per pixel (the shifter uses the low 5 bits of its amount).
 		const uint32_t e0 = ep[0] & 0xffffu, row0 = e0 * MROW;
 		uint32_t acc1 = 0, acc2 = 0, nesc = 0;
-#pragma unroll
-		for (int m = 0; m < 8; m++) {
-			const uint32_t p = ep[m], a5 = (p >> 5) & 0x7ffu, b5 = p >> 21, bh = p >> 16;
-			const uint32_t wa = s_mtx[row0 + a5], wb = s_mtx[row0 + b5];
-			acc1 = __builtin_amdgcn_alignbit(wa >> (p & 31u), acc1, 1);
-			acc1 = __builtin_amdgcn_alignbit(wb >> (bh & 31u), acc1, 1);
-			if (M512) nesc += ((p & 0xffu) >= 127u ? 1u : 0u) + ((bh & 0xffu) >= 127u ? 1u : 0u);
-			if (!is_i) {
-				const uint32_t q = ip[m];
-				const uint32_t va = s_mtx[(q & 0xffffu) * MROW + a5], vb = s_mtx[(q >> 16) * MROW + b5];
-				acc2 = __builtin_amdgcn_alignbit(va >> (p & 31u), acc2, 1);
-				acc2 = __builtin_amdgcn_alignbit(vb >> (bh & 31u), acc2, 1);
-			}
-		}
+		// (the I / P choice is wave-uniform: unswitched by hand -- with the test inside the unrolled loop the compiler
+		//  branches per entry pair and waits for each pair's two matrix words before it issues the next reads)
+		if (is_i) block_tests<M512, false>(ep, ip, s_mtx, row0, acc1, acc2, nesc);
+		else block_tests<M512, true>(ep, ip, s_mtx, row0, acc1, acc2, nesc);
 		const uint32_t count1 = __popc(acc1), count2 = __popc(acc2);
 		const bool copy = !is_i && count2 >= COPY_COUNT;       // COPY has priority, :465
 		const bool fill = !copy && count1 >= FILL_COUNT;
@@ -1667,7 +1679,15 @@ extern "C" agmv_hip_ctx* agmv_hip_create(int device)
 	hipDeviceProp_t prop;
 	CKP(hipGetDeviceProperties(&prop, device));
 	c->n_cu = prop.multiProcessorCount;
-	c->enc_grid = prop.multiProcessorCount * 2;               // 2 workgroups of 512 per CU (LDS/VGPR bound)
+	// persistent grid of k_encode = the workgroups that are resident at once (2 per CU: 69 KB of LDS each)
+	{
+		int per_cu = 0;
+		const size_t lds = (size_t)512 * MROW * 4 + ENC_LDS_EXTRA;
+		(void)hipFuncSetAttribute((const void*)k_encode<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+		if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)k_encode<true>, ENC_T, lds) != hipSuccess || per_cu < 1) per_cu = 2;
+		if (getenv("AGMV_HIP_DEBUG")) fprintf(stderr, "agmv_hip: k_encode: %d workgroup(s) of %d lanes resident per CU (%zu B of LDS each), %d CUs\n", per_cu, ENC_T, lds, c->n_cu);
+		c->enc_grid = prop.multiProcessorCount * per_cu;
+	}
 	return c;
 }
 
