@@ -307,8 +307,8 @@ __device__ __forceinline__ uint32_t lookback(unsigned long long* st, int tile, i
 constexpr int WBLK = 64;                                       // blocks per wave = slice of the workgroup tile
 constexpr size_t CTRL_BYTES = 256;                             // [0] ticket, [1] error, [32..39] phase stamps (ENC_PROF builds)
 
-// K1.  Barrier-free dataflow form.  One workgroup = one tile of ENC_T consecutive 4x4 blocks (ENC_WAVES waves x 64 blocks), one
-// lane = one block for classification/emission, carried through the <=4 frames of its GOP.  The stream of
+// K1.  Barrier-free dataflow form.  One workgroup = one tile of ENC_T consecutive 4x4 blocks (ENC_WAVES waves x 64
+// blocks), one lane = one block for classification/emission, carried through the <=4 frames of its GOP.  The stream of
 // (tile, frame) items a workgroup processes is ONE software pipeline that runs across tile switches; the waves of a
 // workgroup never meet at a barrier inside it -- they exchange single tagged LDS words:
 //   item `it`, every wave:  (Q) quantise with lane = (block, row): wide row loads, each LUT gather instruction covers a
@@ -323,9 +323,9 @@ constexpr size_t CTRL_BYTES = 256;                             // [0] ticket, [1
 //                               of the look-ups), then gbase[it-1][w] = tile offset + bytes of the lower waves.
 // Waves therefore drift apart by up to ~1.5 items, and the phases (look-up issue, look-up wait, LDS, VALU) of the
 // waves sharing a SIMD interleave instead of lining up behind a barrier.  Control words live in 8 slots (it & 7): a
-// wave can finish item `it` only after gbase[it-1] exists, i.e. after EVERY wave has published wsum[it-1]; so when a
-// slot is rewritten for item it+1 all waves have finished item it-2 and with it every read of item it-3's words
-// (4 slots would do; 8 leave room for a copy-out that lags two items).
+// wave can finish item `it` only after gbase[it-1] exists (it waits for that word even when it has no bytes to copy),
+// i.e. after EVERY wave has published wsum[it-1]; so when a slot is rewritten for item it+1 all waves have finished
+// item it-2 and with it every read of item it-3's words (4 slots would do).
 constexpr int DF_SLOTS = 8;
 constexpr int WSLOT = 16 + WBLK * 33 + 16;                     // a wave's stage slot: front pad + worst case + tail pad
 static_assert(WSLOT % 16 == 0 && WSLOT >= 16 + WBLK * 16 * 2, "slot alignment / transpose scratch");
