@@ -2,6 +2,7 @@
 
   python -m libagmv_amd.build          # libagmv_amd/libagmv_hip.so (+ libagmv.so once csrc/*.c exist)
 """
+import fcntl
 import glob
 import os
 import subprocess
@@ -21,24 +22,42 @@ def _stale(target, sources):
     return any(os.path.getmtime(s) > t for s in sources)
 
 
+def _compile(cmd, target, verbose):
+    """compile to a temporary name, then rename: a concurrent reader never sees a half-written library"""
+    tmp = target + ".tmp.%d" % os.getpid()
+    cmd = [tmp if c == target else c for c in cmd]
+    if verbose:
+        print(" ".join(cmd))
+    try:
+        subprocess.run(cmd, check=True)
+        os.replace(tmp, target)
+    finally:
+        if os.path.exists(tmp):
+            os.unlink(tmp)
+
+
 def build(force=False, verbose=False):
+    # one builder at a time (the ranks of a multi-GPU job all call this): the others wait, then find the result fresh
+    with open(os.path.join(HERE, ".build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            return _build(force, verbose)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+
+
+def _build(force=False, verbose=False):
     hip_src = os.path.join(CSRC, "agmv_hip.hip")
     hdrs = glob.glob(os.path.join(ROOT, "include", "*.h"))
     hip_so = os.path.join(HERE, "libagmv_hip.so")
     if force or _stale(hip_so, [hip_src] + hdrs):
-        cmd = [HIPCC, "--offload-arch=" + ARCH, "-O3", "-fPIC", "-shared", "-std=c++17", hip_src, "-o", hip_so]
-        if verbose:
-            print(" ".join(cmd))
-        subprocess.run(cmd, check=True)
+        _compile([HIPCC, "--offload-arch=" + ARCH, "-O3", "-fPIC", "-shared", "-std=c++17", hip_src, "-o", hip_so], hip_so, verbose)
     c_srcs = sorted(glob.glob(os.path.join(CSRC, "*.c")))
     if c_srcs:
         host_so = os.path.join(HERE, "libagmv.so")
         if force or _stale(host_so, c_srcs + hdrs + [hip_so]):
-            cmd = ["gcc", "-O2", "-fPIC", "-shared", "-std=gnu11", "-Wall", "-I" + os.path.join(ROOT, "include")] + c_srcs + \
-                  ["-o", host_so, "-L" + HERE, "-lagmv_hip", "-Wl,-rpath,$ORIGIN", "-lpthread", "-lm"]
-            if verbose:
-                print(" ".join(cmd))
-            subprocess.run(cmd, check=True)
+            _compile(["gcc", "-O2", "-fPIC", "-shared", "-std=gnu11", "-Wall", "-I" + os.path.join(ROOT, "include")] + c_srcs +
+                     ["-o", host_so, "-L" + HERE, "-lagmv_hip", "-Wl,-rpath,$ORIGIN", "-lpthread", "-lm"], host_so, verbose)
     return hip_so
 
 
