@@ -259,6 +259,7 @@ int AGMV_DecodeAGMV(const char* filename, u8 img_type, AGMV_AUDIO_TYPE audio_typ
 void AGMV_ResetVideo(FILE* file, AGMV* agmv);
 Bool AGMV_IsVideoDone(AGMV* agmv);
 void AGMV_SkipForwards(FILE* file, AGMV* agmv, int n);
+void AGMV_SkipForwardsAndDecodeAudio(FILE* file, AGMV* agmv, int n);
 void AGMV_SkipBackwards(FILE* file, AGMV* agmv, int n);
 void AGMV_SkipTo(FILE* file, AGMV* agmv, int n);
 void AGMV_PlayAGMV(FILE* file, AGMV* agmv);

@@ -842,25 +842,73 @@ int AGMV_DecodeAGMV(const char* filename, u8 img_type, AGMV_AUDIO_TYPE audio_typ
 }
 
 /* ------------------------------------------------------------------------------------------
- * playback helpers (reference src/agmv_playback.c:18-115): thin wrappers around the per-frame call
+ * playback helpers, restated from reference src/agmv_playback.c:18-115.  They keep the reference's
+ * bookkeeping exactly: offset_table[] is filled as frames are played or skipped over (not only by
+ * AGMV_ParseAGMV), seeks are relative to frame_count, and the reset offset is 1574 for container
+ * version 1 ONLY (a 512-colour LZ77 file, version 3, is sought to 806 and the next chunk scan walks
+ * over its second palette -- that is what the reference does, src/agmv_playback.c:19-24).
+ * The one deviation is in undefined territory: indices outside offset_table[MAX_OFFSET_TABLE] are
+ * not written / read (the reference has no bound), and a backwards skip past frame 0 lands on frame 0
+ * (the reference stores the negative count into the unsigned field, :86-92).
  * ------------------------------------------------------------------------------------------ */
 void AGMV_ResetVideo(FILE* f, AGMV* a)
 {
-	fseek(f, (a->header.version == 1 || a->header.version == 3) ? 1574 : 806, SEEK_SET);
+	fseek(f, AGMV_GetVersion(a) == 1 ? 1574 : 806, SEEK_SET);     /* :18-26 */
 	a->frame_count = 0;
-	if (a->audio_track) a->audio_track->start_point = 0;
 }
-Bool AGMV_IsVideoDone(AGMV* a) { return a->frame_count >= AGMV_GetNumberOfFrames(a) ? TRUE : FALSE; }
+
+Bool AGMV_IsVideoDone(AGMV* a) { return a->frame_count >= AGMV_GetNumberOfFrames(a) ? TRUE : FALSE; }   /* :28-33 */
+
+static void note_offset(FILE* f, AGMV* a)
+{
+	if (a->frame_count < MAX_OFFSET_TABLE) a->offset_table[a->frame_count] = (u32)ftell(f);
+}
+
+/* :35-83: walk forward over NextIFrame(n, frame_count) frame chunks, recording where each one starts */
+static void skip_forwards(FILE* f, AGMV* a, int n, int decode_audio)
+{
+	const int audio = AGMV_GetTotalAudioDuration(a) != 0;
+	int i;
+	n = AGMV_NextIFrame(n, (int)a->frame_count);
+	for (i = 0; i < n; i++) {
+		AGMV_FindNextFrameChunk(f);
+		note_offset(f, a);
+		a->frame_count++;
+		AGMV_SkipFrameChunk(f);
+		if (audio) {
+			AGMV_FindNextAudioChunk(f);
+			if (decode_audio) AGMV_DecodeAudioChunk(f, a); else AGMV_SkipAudioChunk(f);
+		}
+	}
+}
+
+void AGMV_SkipForwards(FILE* f, AGMV* a, int n) { skip_forwards(f, a, n, 0); }
+void AGMV_SkipForwardsAndDecodeAudio(FILE* f, AGMV* a, int n) { skip_forwards(f, a, n, 1); }
+
+void AGMV_SkipBackwards(FILE* f, AGMV* a, int n)                 /* :85-94 */
+{
+	int fc = (int)a->frame_count;
+	n = AGMV_PrevIFrame(n, fc);
+	fc -= n;
+	if (fc < 0) fc = 0;
+	a->frame_count = (u32)fc;
+	if (fc < MAX_OFFSET_TABLE) fseek(f, (long)a->offset_table[fc], SEEK_SET);
+}
+
+/* :96-104 ("only call after all frames have been read": offset_table must hold entry n) */
 void AGMV_SkipTo(FILE* f, AGMV* a, int n)
 {
 	n = AGMV_SkipToNearestIFrame(n);
-	if (n >= 0 && (u32)n < AGMV_GetNumberOfFrames(a) && n < MAX_OFFSET_TABLE) { fseek(f, (long)a->offset_table[n], SEEK_SET); a->frame_count = (u32)n; }
+	if (n >= 0 && (u32)n < AGMV_GetNumberOfFrames(a) && n < MAX_OFFSET_TABLE) {
+		fseek(f, (long)a->offset_table[n], SEEK_SET);
+		a->frame_count = (u32)n;
+	}
 }
-void AGMV_SkipForwards(FILE* f, AGMV* a, int n) { AGMV_SkipTo(f, a, AGMV_NextIFrame((int)a->frame_count + n, 0)); }
-void AGMV_SkipBackwards(FILE* f, AGMV* a, int n) { int t = (int)a->frame_count - n; AGMV_SkipTo(f, a, t < 0 ? 0 : AGMV_PrevIFrame(t, 0)); }
-void AGMV_PlayAGMV(FILE* f, AGMV* a)
+
+void AGMV_PlayAGMV(FILE* f, AGMV* a)                            /* :106-119 */
 {
 	AGMV_FindNextFrameChunk(f);
+	note_offset(f, a);
 	AGMV_DecodeFrameChunk(f, a);
-	if (AGMV_GetTotalAudioDuration(a) != 0) { AGMV_FindNextAudioChunk(f); AGMV_DecodeAudioChunk(f, a); }
+	if (AGMV_GetTotalAudioDuration(a) != 0) { AGMV_FindNextAudioChunk(f); AGMV_SkipAudioChunk(f); }
 }

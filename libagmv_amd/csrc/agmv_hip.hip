@@ -62,6 +62,26 @@ extern "C" const char* agmv_hip_last_error(void) { return g_err; }
 #ifndef ENC_PIXAUX
 #define ENC_PIXAUX 2          /* cache policy of the pixel loads: 2 = nt (streamed once; keeps L2 for the table), 0 = default */
 #endif
+#ifndef ENC_LUTAUX
+#define ENC_LUTAUX 0          /* cache policy of the table look-ups */
+#endif
+#ifndef ENC_MAXWPE
+#define ENC_MAXWPE 0          /* != 0: tell the compiler that no more than this many waves share a SIMD anyway (LDS bounds the residency), so it may spend registers on keeping LDS reads in flight */
+#endif
+#if ENC_MAXWPE
+#define ENC_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(ENC_MAXWPE, ENC_MAXWPE)))
+#else
+#define ENC_WAVES_ATTR
+#endif
+#ifndef ENC_PFLATE
+#define ENC_PFLATE 3          /* where the next item's pixel loads are issued: 0 behind the look-ups, 1 after emit (ahead of the tile-offset wait), 2 after classify, 3 after the copy-out (measured best: synth 0.730 vs 0.768 ms per 256 frames) */
+#endif
+#ifndef ENC_HDUP
+#define ENC_HDUP 0            /* 1: no look-up for a pixel that equals its left neighbour in the lane's row segment (see the Q phase) */
+#endif
+#ifndef ENC_CC
+#define ENC_CC 0              /* log2 of the slots of the workgroup's colour cache in LDS (0 = no cache; see the Q phase) */
+#endif
 constexpr int ENC_T = ENC_T_OVERRIDE;          // threads per encode workgroup = 4x4 blocks per tile
 constexpr int ENC_WAVES = ENC_T / 64;
 static_assert(ENC_WAVES >= 1 && ENC_WAVES <= 16, "the per-wave offsets are scanned inside one 16-lane row");
@@ -305,7 +325,7 @@ __device__ __forceinline__ uint32_t lookback(unsigned long long* st, int tile, i
 }
 
 constexpr int WBLK = 64;                                       // blocks per wave = slice of the workgroup tile
-constexpr size_t CTRL_BYTES = 256;                             // [0] ticket, [1] error, [32..39] phase stamps (ENC_PROF builds)
+constexpr size_t CTRL_BYTES = 256;                             // [0] ticket, [1] error, [32..42] phase stamps (ENC_PROF builds)
 
 // K1.  Barrier-free dataflow form.  One workgroup = one tile of ENC_T consecutive 4x4 blocks (ENC_WAVES waves x 64
 // blocks), one lane = one block for classification/emission, carried through the <=4 frames of its GOP.  The stream of
@@ -335,7 +355,14 @@ constexpr int C_TTOTAL = C_ARRIVE + DF_SLOTS;                  // [slot]        
 constexpr int C_GBASE = C_TTOTAL + DF_SLOTS;                   // [slot][wave][2]   frame byte offset of the wave, tag
 constexpr int C_TICKET = C_GBASE + DF_SLOTS * ENC_WAVES * 2;   // [slot][2]         ticket of tile sequence number s, s
 constexpr int C_END = C_TICKET + DF_SLOTS * 2;
-constexpr size_t ENC_LDS_EXTRA = 2 * ENC_WAVES * WSLOT + C_END * 4;
+constexpr uint32_t CC_SLOTS = ENC_CC ? (1u << ENC_CC) : 0u;
+constexpr uint32_t CC_MUL = 0x9E3779u;                         // odd: colour -> colour * CC_MUL mod 2^24 is a bijection
+constexpr uint32_t CC_SHIFT = 24 - ENC_CC - 2;                 // slot = the top ENC_CC bits of the 24, as a byte offset
+constexpr uint32_t CC_AMASK = (CC_SLOTS - 1u) << 2;
+constexpr uint32_t CC_TMASK = (1u << (24 - ENC_CC)) - 1u;      // tag = the remaining low bits
+constexpr uint32_t CC_VALID = 1u << (24 - ENC_CC);
+static_assert(ENC_CC == 0 || (ENC_CC >= 8 && ENC_CC <= 15), "cache word = valid | tag (24 - ENC_CC bits) | entry (9 bits)");
+constexpr size_t ENC_LDS_EXTRA = 2 * ENC_WAVES * WSLOT + C_END * 4 + CC_SLOTS * 4;
 
 typedef uint16_t __attribute__((aligned(1))) u16u;          // byte-aligned 16/32-bit LDS stores (DS unaligned mode)
 typedef uint32_t __attribute__((aligned(1))) u32u;
@@ -383,18 +410,34 @@ template <bool M512, bool PFRAME>
 __device__ __forceinline__ void block_tests(const uint32_t (&ep)[8], const uint32_t (&ip)[8], const uint32_t* s_mtx,
                                             uint32_t row0, uint32_t& acc1, uint32_t& acc2, uint32_t& nesc)
 {
+	// All matrix words of the block are requested BEFORE the first one is used (two batches of 16 for a P-frame: the LDS
+	// counter tracks 15 reads): left to itself the compiler keeps two or three reads in flight and waits a dozen times,
+	// and with four waves per SIMD those LDS round trips are exposed.
+	uint32_t wa[8], wb[8], va[8], vb[8];
 #pragma unroll
 	for (int m = 0; m < 8; m++) {
-		const uint32_t p = ep[m], a5 = (p >> 5) & 0x7ffu, b5 = p >> 21, bh = p >> 16;
-		const uint32_t wa = s_mtx[row0 + a5], wb = s_mtx[row0 + b5];
-		acc1 = __builtin_amdgcn_alignbit(wa >> (p & 31u), acc1, 1);
-		acc1 = __builtin_amdgcn_alignbit(wb >> (bh & 31u), acc1, 1);
+		const uint32_t p = ep[m], a5 = (p >> 5) & 0x7ffu, b5 = p >> 21;
+		wa[m] = lds_ld(s_mtx + row0 + a5);
+		wb[m] = lds_ld(s_mtx + row0 + b5);
+	}
+	if (PFRAME) {
+#pragma unroll
+		for (int m = 0; m < 8; m++) {
+			const uint32_t p = ep[m], a5 = (p >> 5) & 0x7ffu, b5 = p >> 21, q = ip[m];
+			va[m] = lds_ld(s_mtx + (q & 0xffffu) * MROW + a5);
+			vb[m] = lds_ld(s_mtx + (q >> 16) * MROW + b5);
+		}
+	}
+	__builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+	for (int m = 0; m < 8; m++) {
+		const uint32_t p = ep[m], bh = p >> 16;
+		acc1 = __builtin_amdgcn_alignbit(wa[m] >> (p & 31u), acc1, 1);
+		acc1 = __builtin_amdgcn_alignbit(wb[m] >> (bh & 31u), acc1, 1);
 		if (M512) nesc += ((p & 0xffu) >= 127u ? 1u : 0u) + ((bh & 0xffu) >= 127u ? 1u : 0u);
 		if (PFRAME) {
-			const uint32_t q = ip[m];
-			const uint32_t va = s_mtx[(q & 0xffffu) * MROW + a5], vb = s_mtx[(q >> 16) * MROW + b5];
-			acc2 = __builtin_amdgcn_alignbit(va >> (p & 31u), acc2, 1);
-			acc2 = __builtin_amdgcn_alignbit(vb >> (bh & 31u), acc2, 1);
+			acc2 = __builtin_amdgcn_alignbit(va[m] >> (p & 31u), acc2, 1);
+			acc2 = __builtin_amdgcn_alignbit(vb[m] >> (bh & 31u), acc2, 1);
 		}
 	}
 }
@@ -407,13 +450,17 @@ struct EncGeo {
 };
 
 template <bool M512>
-__global__ __launch_bounds__(ENC_T, ENC_WPE) void k_encode(EncArgs A)
+__global__ __launch_bounds__(ENC_T, ENC_WPE) ENC_WAVES_ATTR void k_encode(EncArgs A)
 {
 	constexpr int NROWS = M512 ? 512 : 256;
 	extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
 	uint32_t* s_mtx = (uint32_t*)smem;                         // NROWS * MROW dwords
 	uint8_t* s_stage0 = smem + NROWS * MROW * 4;               // [2][ENC_WAVES] stage slots
 	uint32_t* s_ctl = (uint32_t*)(s_stage0 + 2 * ENC_WAVES * WSLOT);
+#if ENC_CC
+	uint32_t* s_cc = s_ctl + C_END;                            // the colour cache (see the Q phase)
+	for (int i = threadIdx.x; i < (int)CC_SLOTS; i += ENC_T) s_cc[i] = 0;
+#endif
 
 	const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 	const uint32_t npx = A.w * A.h;
@@ -460,6 +507,9 @@ __global__ __launch_bounds__(ENC_T, ENC_WPE) void k_encode(EncArgs A)
 		g.path = (g.wbase + WBLK > A.nblk || g.wbx + WBLK > 2 * A.bw) ? 2 : (g.wbx + WBLK > A.bw ? 1 : 0);
 	};
 	auto load_frame = [&](const EncGeo& g, const uint32_t* fp, uint4 (&dst)[4]) {
+#ifdef ABL_PXHOT
+		fp = A.pix;                                            // ablation: every item reads frame 0 (L2 / Infinity-Cache hits instead of HBM)
+#endif
 		const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)fp, 0, (int)(npx * 4u), 0x00020000);
 		const uint32_t w3b = 12u * A.w;
 		if (g.path == 0) {
@@ -495,7 +545,7 @@ __global__ __launch_bounds__(ENC_T, ENC_WPE) void k_encode(EncArgs A)
 	uint32_t tk = 0;
 
 #ifdef ENC_PROF
-	uint32_t prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+	uint32_t prof[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 	unsigned long long pt = __builtin_amdgcn_s_memtime();
 #define PSTAMP(k) do { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); prof[k] += (uint32_t)(n_ - pt); pt = n_; } while (0)
 #else
@@ -541,7 +591,9 @@ __global__ __launch_bounds__(ENC_T, ENC_WPE) void k_encode(EncArgs A)
 			// (see the header comment) -- a wave of blocks past the end of the frame must not run rounds ahead and recycle
 			// control slots the others still read
 			const uint32_t* gb = &s_ctl[C_GBASE + (pslot * ENC_WAVES + wave) * 2];
+#ifndef ABL_NOSYNC
 			lds_wait(gb + 1, it, 0, A.ctrl, lane);
+#endif
 			asm volatile("" ::: "memory");
 			if (p_len == 0) return;
 			const uint32_t base = __builtin_amdgcn_readfirstlane(lds_ld(gb));
@@ -573,59 +625,124 @@ __global__ __launch_bounds__(ENC_T, ENC_WPE) void k_encode(EncArgs A)
 			}
 			if (wave == 0 && lane == 0) tk = atomicAdd(A.ctrl, 1u);   // ticket of the NEXT tile, drawn a tile ahead
 		}
+		// ---- next item's pixels (next frame, or the first frame of the NEXT tile, whose ticket was drawn one tile earlier)
+		bool have_next = true;
+		auto prefetch_next = [&]() {
+			asm volatile("" ::: "memory");
+			if (new_tile && wave == 0) {                           // publish the next tile's ticket to the other waves
+				const uint32_t tkv = __builtin_amdgcn_readfirstlane(tk);
+				if (lane == 0) {
+					uint32_t* tw = &s_ctl[C_TICKET + ((seq + 1) & (DF_SLOTS - 1)) * 2];
+					lds_st(tw, tkv);
+					asm volatile("" ::: "memory");
+					lds_st(tw + 1, seq + 1);
+				}
+			}
+			if (f + 1 < g.f_hi) {
+				load_frame(g, A.pix + (size_t)(f + 1) * npx, px);
+			} else {
+				const uint32_t* tw = &s_ctl[C_TICKET + ((seq + 1) & (DF_SLOTS - 1)) * 2];
+				lds_wait(tw + 1, seq + 1, 0, A.ctrl, lane);
+				asm volatile("" ::: "memory");
+				const uint32_t nt = __builtin_amdgcn_readfirstlane(lds_ld(tw));
+				have_next = nt < A.total_tiles;
+				if (have_next) {
+					setup(nt, gn);
+					load_frame(gn, A.pix + (size_t)gn.f_lo * npx, px);
+				}
+			}
+		};
+#ifdef ENC_PROF
+		PSTAMP(9);                                             // loop top: bookkeeping, duty status prefetch, I-frame entry plane
+		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+		PSTAMP(8);                                             // wait for this item's pixels
+		prof[10]++;
+#endif
 #if ENC_PRIO
 		__builtin_amdgcn_s_setprio(ENC_PRIO);
 #endif
 		// ---- (Q) colour -> entry through the exact table, lane = (block, row)
 		uint32_t eq[16];
+		const uint32_t pxv[16] = {px[0].x, px[0].y, px[0].z, px[0].w, px[1].x, px[1].y, px[1].z, px[1].w,
+		                          px[2].x, px[2].y, px[2].z, px[2].w, px[3].x, px[3].y, px[3].z, px[3].w};
 #ifdef ABL_SMALLLUT
 #define LUT_OFF(c) (lut_offset(c) & 0x1FFFFEu)
 #else
 #define LUT_OFF(c) lut_offset(c)
 #endif
+#if ENC_CC
+		// Colour cache.  The CU's L1 serves ONE lane per clock once the four lanes of a quad read different addresses
+		// (tools/micro/tcpbench.hip: 64 clocks per look-up instruction, against 16 when every quad reads one address), i.e.
+		// one pixel per clock per CU = 2.2 TB/s of pixels: the look-ups, not HBM, bound the encoder.  So the lanes first
+		// probe a direct-mapped table of (colour -> entry) words in LDS, shared by the workgroup, and only the lanes that miss
+		// go to the global table (EXEC-masked: the L1's time follows the active lanes); they add their colour afterwards.
+		// A slot is ONE 32-bit word {valid, tag, entry}: slot index and tag together are a bijection of the 24-bit colour
+		// (h = colour * odd constant mod 2^24), so a hit is the entry of exactly that colour; a word is read and written
+		// whole, so concurrent waves see either the old or the new pair, never a mixture.  Zeroed at kernel start (a launch
+		// has one palette).
+		uint32_t hh[16];
+		unsigned long long missm[16];
+		{
+			uint32_t cw[16];
 #pragma unroll
-		for (int i = 0; i < 4; i++) {
-#ifdef ABL_NOGATHER
-			eq[i * 4 + 0] = px[i].x & 0x1FFu; eq[i * 4 + 1] = px[i].y & 0x1FFu;
-			eq[i * 4 + 2] = px[i].z & 0x1FFu; eq[i * 4 + 3] = px[i].w & 0x1FFu;
+			for (int k = 0; k < 16; k++) {
+				hh[k] = __umul24(pxv[k], CC_MUL);                  // bits 23:0 of the product: a bijection of the colour
+				cw[k] = *(const lds_u32*)((const uint8_t*)s_cc + ((hh[k] >> CC_SHIFT) & CC_AMASK));
+			}
+#pragma unroll
+			for (int k = 0; k < 16; k++) {
+				const bool miss = (cw[k] >> 9) != ((hh[k] & CC_TMASK) | CC_VALID);
+				missm[k] = __ballot(miss);
+				eq[k] = cw[k] & 0x1FFu;
+				if (miss) eq[k] = (uint16_t)__builtin_amdgcn_raw_buffer_load_b16(lut_rs, LUT_OFF(pxv[k]), 0, ENC_LUTAUX);
+			}
+		}
+#elif ENC_HDUP
+		// The CU's L1 serves ONE lane per clock once the four lanes of a quad read different addresses (64 clocks per look-up
+		// instruction; 16 when every quad reads one address; nothing for a lane that is masked off -- tools/micro/tcpbench.hip),
+		// so the look-ups, not HBM, bound the encoder on anything but flat content.  A pixel that equals its left neighbour in
+		// the lane's row segment has the neighbour's entry: its look-up is not issued (EXEC-masked; skipped altogether when no
+		// lane of the wave needs it) and the entry is copied once the neighbour's has landed.  Exact: the table is a function
+		// of the pixel.
+		unsigned long long dupm[12];
+#pragma unroll
+		for (int k = 0; k < 16; k++) {
+			bool dup = false;
+			if (k & 3) { dup = pxv[k] == pxv[k - 1]; dupm[(k >> 2) * 3 + (k & 3) - 1] = __ballot(dup); }
+			eq[k] = 0;
+			if (!dup) eq[k] = (uint16_t)__builtin_amdgcn_raw_buffer_load_b16(lut_rs, LUT_OFF(pxv[k]), 0, ENC_LUTAUX);
+		}
 #else
-			eq[i * 4 + 0] = (uint16_t)__builtin_amdgcn_raw_buffer_load_b16(lut_rs, LUT_OFF(px[i].x), 0, 0);
-			eq[i * 4 + 1] = (uint16_t)__builtin_amdgcn_raw_buffer_load_b16(lut_rs, LUT_OFF(px[i].y), 0, 0);
-			eq[i * 4 + 2] = (uint16_t)__builtin_amdgcn_raw_buffer_load_b16(lut_rs, LUT_OFF(px[i].z), 0, 0);
-			eq[i * 4 + 3] = (uint16_t)__builtin_amdgcn_raw_buffer_load_b16(lut_rs, LUT_OFF(px[i].w), 0, 0);
+#pragma unroll
+		for (int k = 0; k < 16; k++) {
+#ifdef ABL_NOGATHER
+			eq[k] = pxv[k] & 0x1FFu;
+#else
+			eq[k] = (uint16_t)__builtin_amdgcn_raw_buffer_load_b16(lut_rs, LUT_OFF(pxv[k]), 0, ENC_LUTAUX);
 #endif
 		}
+#endif
 		PSTAMP(0);
-		// ---- next item's pixels, issued right BEHIND the look-ups (the memory counter retires in order: ahead of them
-		// they would have to land before the first entry is usable), and before the wait for the entries
-		asm volatile("" ::: "memory");
-		bool have_next = true;
-		if (new_tile && wave == 0) {                           // publish the next tile's ticket to the other waves
-			const uint32_t tkv = __builtin_amdgcn_readfirstlane(tk);
-			if (lane == 0) {
-				uint32_t* tw = &s_ctl[C_TICKET + ((seq + 1) & (DF_SLOTS - 1)) * 2];
-				lds_st(tw, tkv);
-				asm volatile("" ::: "memory");
-				lds_st(tw + 1, seq + 1);
-			}
-		}
-		if (f + 1 < g.f_hi) {
-			load_frame(g, A.pix + (size_t)(f + 1) * npx, px);
-		} else {
-			const uint32_t* tw = &s_ctl[C_TICKET + ((seq + 1) & (DF_SLOTS - 1)) * 2];
-			lds_wait(tw + 1, seq + 1, 0, A.ctrl, lane);
-			asm volatile("" ::: "memory");
-			const uint32_t nt = __builtin_amdgcn_readfirstlane(lds_ld(tw));
-			have_next = nt < A.total_tiles;
-			if (have_next) {
-				setup(nt, gn);
-				load_frame(gn, A.pix + (size_t)gn.f_lo * npx, px);
-			}
-		}
+		// issued right BEHIND the look-ups (the memory counter retires in order: ahead of them they would have to land
+		// before the first entry is usable), and before the wait for the entries
+#if ENC_PFLATE == 0
+		prefetch_next();
+#endif
 #if ENC_PRIO
 		__builtin_amdgcn_s_setprio(0);
 #endif
 		PSTAMP(2);
+#if ENC_HDUP
+#pragma unroll
+		for (int k = 0; k < 16; k++)                               // left to right: a run of equal pixels takes the first one's entry
+			if ((k & 3) && __builtin_amdgcn_inverse_ballot_w64(dupm[(k >> 2) * 3 + (k & 3) - 1])) eq[k] = eq[k - 1];
+#endif
+#if ENC_CC
+#pragma unroll
+		for (int k = 0; k < 16; k++)                               // the lanes that missed add {tag, entry} of their colour
+			if (__builtin_amdgcn_inverse_ballot_w64(missm[k]))
+				*(lds_u32*)((uint8_t*)s_cc + ((hh[k] >> CC_SHIFT) & CC_AMASK)) = (((hh[k] & CC_TMASK) | CC_VALID) << 9) | eq[k];
+#endif
 		// [block][pixel] u16 table in the wave's scratch; a lane writes its row: 8 bytes at i*512 + lane*8
 #pragma unroll
 		for (int i = 0; i < 4; i++) {
@@ -652,8 +769,12 @@ __global__ __launch_bounds__(ENC_T, ENC_WPE) void k_encode(EncArgs A)
 		uint32_t acc1 = 0, acc2 = 0, nesc = 0;
 		// (the I / P choice is wave-uniform: unswitched by hand -- with the test inside the unrolled loop the compiler
 		//  branches per entry pair and waits for each pair's two matrix words before it issues the next reads)
+#ifdef ABL_NOCMP
+		acc1 = 0xFFFFu; acc2 = 0xFFFFu; (void)row0;                   // ablation: every block FILL / COPY without reading the matrix
+#else
 		if (is_i) block_tests<M512, false>(ep, ip, s_mtx, row0, acc1, acc2, nesc);
 		else block_tests<M512, true>(ep, ip, s_mtx, row0, acc1, acc2, nesc);
+#endif
 		const uint32_t count1 = __popc(acc1), count2 = __popc(acc2);
 		const bool copy = !is_i && count2 >= COPY_COUNT;       // COPY has priority, :465
 		const bool fill = !copy && count1 >= FILL_COUNT;
@@ -697,12 +818,19 @@ __global__ __launch_bounds__(ENC_T, ENC_WPE) void k_encode(EncArgs A)
 			}
 		}
 		PSTAMP(4);
+#if ENC_PFLATE == 2
+		prefetch_next();
+#endif
 		// ---- (E) emit this block's bytes into the wave's stage slot
 		// Codes are built two at a time in packed 16-bit lanes and written as {code, index} byte PAIRS at byte-granular
 		// LDS addresses (gfx950 runs DS in unaligned mode): when an entry has no escape byte its pair's second byte is
 		// overwritten by the next pair, and the one byte a block may spill past its end is the next block's flag --
 		// which is why the flags are written last.  The LDS unit executes a wave's writes in program order.
+#ifdef ABL_NOEMIT
+		if (false) {
+#else
 		if (g.valid) {
+#endif
 			uint8_t* sp = wslot + 16 + incl - len;
 			if (!copy && !fill) {
 				if (M512) {
@@ -736,7 +864,13 @@ __global__ __launch_bounds__(ENC_T, ENC_WPE) void k_encode(EncArgs A)
 			sp[0] = copy ? COPY_FLAG : (fill ? FILL_FLAG : NORMAL_FLAG);
 		}
 		PSTAMP(5);
+#if ENC_PFLATE == 1
+		prefetch_next();                                       // ahead of the wait for the tile offset: an issue that blocks on a full memory pipeline blocks nothing else here
+#endif
 		if (have_prev) copy_out_prev();
+#if ENC_PFLATE == 3
+		prefetch_next();
+#endif
 		PSTAMP(7);
 
 		// ---- next item
@@ -752,7 +886,7 @@ __global__ __launch_bounds__(ENC_T, ENC_WPE) void k_encode(EncArgs A)
 	}
 #ifdef ENC_PROF
 	if (lane == 0)
-		for (int k = 0; k < 8; k++) atomicAdd(A.ctrl + 32 + k, prof[k] >> 10);
+		for (int k = 0; k < 11; k++) atomicAdd(A.ctrl + 32 + k, k == 10 ? prof[k] : prof[k] >> 6);
 #endif
 }
 
@@ -1848,12 +1982,15 @@ extern "C" int agmv_hip_check(agmv_hip_ctx* c, void* stream)
 	CK(hipMemcpy(ctrl, c->d_ctrl, 16, hipMemcpyDeviceToHost));
 #ifdef ENC_PROF
 	{
-		uint32_t pr[8];
-		CK(hipMemcpy(pr, c->d_ctrl + 32, 32, hipMemcpyDeviceToHost));
+		uint32_t pr[12];
+		CK(hipMemcpy(pr, c->d_ctrl + 32, 44, hipMemcpyDeviceToHost));
 		double tot = 0;
-		for (int k = 0; k < 8; k++) tot += pr[k];
-		fprintf(stderr, "k_encode phases (%% of wave time): loop top + look-up issue %.1f | look-up wait + park %.1f | prefetch+ticket %.1f | duty %.1f | classify+scan %.1f | emit %.1f | wait for gbase %.1f | copy-out %.1f\n",
-		        100 * pr[0] / tot, 100 * pr[1] / tot, 100 * pr[2] / tot, 100 * pr[3] / tot, 100 * pr[4] / tot, 100 * pr[5] / tot, 100 * pr[6] / tot, 100 * pr[7] / tot);
+		for (int k = 0; k < 10; k++) tot += pr[k];
+		const double per = 64.0 / (pr[10] ? pr[10] : 1);        // shader cycles per item of ONE wave (the counters hold cycles / 64 summed over the waves)
+		fprintf(stderr, "k_encode phases, cycles per wave-item (%% of wave time): loop top %.0f (%.1f) | pixel wait %.0f (%.1f) | look-up issue %.0f (%.1f) | prefetch issue + ticket %.0f (%.1f) | "
+		        "look-up wait + park %.0f (%.1f) | duty %.0f (%.1f) | transpose + classify + scan %.0f (%.1f) | emit %.0f (%.1f) | wait for gbase %.0f (%.1f) | copy-out %.0f (%.1f) | total %.0f, %u wave-items\n",
+		        pr[9] * per, 100 * pr[9] / tot, pr[8] * per, 100 * pr[8] / tot, pr[0] * per, 100 * pr[0] / tot, pr[2] * per, 100 * pr[2] / tot, pr[1] * per, 100 * pr[1] / tot,
+		        pr[3] * per, 100 * pr[3] / tot, pr[4] * per, 100 * pr[4] / tot, pr[5] * per, 100 * pr[5] / tot, pr[6] * per, 100 * pr[6] / tot, pr[7] * per, 100 * pr[7] / tot, tot * per, pr[10]);
 	}
 #endif
 	if (ctrl[1]) { snprintf(g_err, sizeof(g_err), "agmv_hip: look-back timed out inside k_encode (device error word %u)", ctrl[1]); return -2; }

@@ -32,15 +32,15 @@ def lib_path():
     return os.environ.get("AGMV_HIP_LIB") or os.path.join(HERE, "libagmv_hip.so")
 
 
-_lib = None
+_libs = {}
 
 
-def load_library():
-    """dlopen libagmv_hip.so (built in-tree by libagmv_amd/build.py). No fallback."""
-    global _lib
-    if _lib is not None:
-        return _lib
-    p = lib_path()
+def load_library(path=None):
+    """dlopen libagmv_hip.so (built in-tree by libagmv_amd/build.py). No fallback.
+    `path` selects another build of the same source (tools/probe_multi.py times several in one process)."""
+    p = path or lib_path()
+    if p in _libs:
+        return _libs[p]
     if not os.path.exists(p):
         raise HipUnavailable("%s is missing: run `python -m libagmv_amd.build` (or "
                              "__graft_entry__.build()); the AGMV hot path has no CPU fallback" % p)
@@ -79,7 +79,7 @@ def load_library():
               L.agmv_hip_decode_frames, L.agmv_hip_synth_dev, L.agmv_hip_interp_dev,
               L.agmv_hip_histogram_dev, L.agmv_hip_check):
         f.restype = C.c_int
-    _lib = L
+    _libs[p] = L
     return L
 
 
@@ -92,8 +92,8 @@ class AgmvHip:
     (uint8 / int16 / int32 storage: torch has no unsigned 16/32-bit arithmetic types, the bytes
     are what matters) and run on torch's current stream."""
 
-    def __init__(self, device=0):
-        self.L = load_library()
+    def __init__(self, device=0, lib=None):
+        self.L = load_library(lib)
         self.ctx = self.L.agmv_hip_create(int(device))
         if not self.ctx:
             raise HipUnavailable(self.L.agmv_hip_last_error().decode())
