@@ -67,10 +67,12 @@ def host_lib():
     return L
 
 
-def cpu_baseline(wl, p0, p1, frames_np, gpu_bits):
+def cpu_baseline(wl, p0, p1, frames_np, gpu_bits, gpu_pix=None):
     """the reference's own compiled loops (oracle/_ref, kind 'reference') or, where that build is absent, the
-    oracle restatement (kind 'port') on a bounded sample of the same clip, one host thread.  Also a free parity
-    check: the sample's bitstreams must equal what the GPU produced for those frames."""
+    oracle restatement (kind 'port') on a bounded sample of the same clip, one host thread.  The DECODE leg is always
+    the restatement ('port': the compiled reference's decoder is file-coupled to its LZ stage), which the tests pin
+    against the reference; `legs` says which is which.  Also a free parity check: the sample's bitstreams AND decoded
+    pixels must equal what the GPU produced for those frames."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracles as O
     W, H = wl["W"], wl["H"]
@@ -82,14 +84,17 @@ def cpu_baseline(wl, p0, p1, frames_np, gpu_bits):
         t0 = time.perf_counter()
         b = enc.encode(f)
         t1 = time.perf_counter()
-        dec.decode(b)
+        pix = dec.decode(b)
         t2 = time.perf_counter()
         t_enc += t1 - t0
         t_dec += t2 - t1
         if gpu_bits is not None and not (len(b) == len(gpu_bits[k]) and (b == gpu_bits[k]).all()):
             raise SystemExit("bench: GPU bitstream of frame %d differs from the %s CPU path" % (k, kind))
+        if gpu_pix is not None and not (pix == gpu_pix[k]).all():
+            raise SystemExit("bench: GPU decode of frame %d differs from the CPU decoder" % k)
     n = len(frames_np)
     return {"value": round(n / (t_enc + t_dec), 4), "unit": "frames/s", "cores": 1, "kind": kind,
+            "legs": {"encode": kind, "decode": "port"},
             "sample": "first %d encoded frames of the same clip (%dx%d): AGMV_FindNearestEntry per pixel + "
                       "Assemble{I,P}FrameBitstream (%.2f s/frame) then parse+reconstruct (%.4f s/frame); "
                       "LZSS excluded on both sides" % (n, W, H, t_enc / n, t_dec / n),
@@ -259,7 +264,8 @@ def main():
             n_cpu = min(n_cpu, n_enc)
             f_np = frames[:n_cpu].cpu().numpy().view(np.uint32)
             gpu_bits = [out[f, :int(usz[f])].cpu().numpy() for f in range(n_cpu)]
-            res["cpu_baseline"] = cpu_baseline(wl, p0, p1, list(f_np), gpu_bits)
+            gpu_pix = [dec[f].cpu().numpy().view(np.uint32).reshape(-1) for f in range(n_cpu)]
+            res["cpu_baseline"] = cpu_baseline(wl, p0, p1, list(f_np), gpu_bits, gpu_pix)
         print(json.dumps(res))
     if dist is not None:
         dist.barrier()

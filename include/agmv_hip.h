@@ -78,6 +78,39 @@ int agmv_hip_encode_frames(agmv_hip_ctx* ctx, const uint32_t* h_pix, uint32_t n_
                            uint8_t* h_out, size_t out_stride, uint32_t* h_sizes,
                            uint16_t* h_iframe_entries);
 
+/* The same on planes of ENTRIES instead of pixels: word k of frame f holds pal_num << 8 | index of pixel k.  The
+   quantisation is skipped; classification and assembly are those of AGMV_AssembleIFrameBitstream /
+   AGMV_AssemblePFrameBitstream on that AGMV_ENTRY plane (reference src/agmv_encode.c:354-436, :438-527). */
+int agmv_hip_encode_entries_dev(agmv_hip_ctx* ctx, const uint32_t* d_entries, uint32_t n_frames,
+                                uint32_t w, uint32_t h, uint32_t first_frame_count,
+                                uint8_t* d_out, size_t out_stride, uint32_t* d_sizes,
+                                uint16_t* d_iframe_entries, void* stream);
+int agmv_hip_encode_entries(agmv_hip_ctx* ctx, const uint32_t* h_entries, uint32_t n_frames,
+                            uint32_t w, uint32_t h, uint32_t first_frame_count,
+                            uint8_t* h_out, size_t out_stride, uint32_t* h_sizes,
+                            uint16_t* h_iframe_entries);
+
+/* nearest colour / entry of n pixels against palettes that need not be the context's (no table is built):
+   AGMV_FindNearestColor (mode512 = 0, entry = index in p0) / AGMV_FindNearestEntry (mode512 = 1), reference
+   src/agmv_utils.c:785-816, :851-895.  Host buffers, synchronous; the device scratch is cached in the context. */
+int agmv_hip_nearest(agmv_hip_ctx* ctx, const uint32_t p0[256], const uint32_t p1[256], int mode512,
+                     const uint32_t* h_pix, size_t n, uint16_t* h_entries);
+
+/* number of the 16 colour pairs (a[k], b[k]) that are within +-2 on R, G and B: the count AGMV_CompareIFrameBlock
+   (b = the block's reference colour 16 times) and AGMV_ComparePFrameBlock (b = the I-frame entries' colours) return
+   (reference src/agmv_encode.c:302-352, :240-300).  Returns 0..16, negative on error. */
+int agmv_hip_within2_count(agmv_hip_ctx* ctx, const uint32_t a[16], const uint32_t b[16]);
+
+/* Notes on a context:
+ *  - device memory: 512 MiB of address space for the colour -> entry table (32 MiB of it populated, see
+ *    k_lut_build in agmv_hip.hip), plus per-batch work areas grown on demand (look-back status 8 B per tile and
+ *    frame, parser workspace <= 15 % of the bitstream slab);
+ *  - the encode entry points of ONE context share its look-back status and control words: a second encode is
+ *    ordered behind the first (on another stream it waits for it through an event); use one context per
+ *    concurrent encoder;
+ *  - a device-side wait that runs into its bound (never observed on a healthy GPU) makes agmv_hip_check fail AND
+ *    overwrites every size of that batch with 0xFFFFFFFF, so the bytes cannot be taken for valid ones. */
+
 /* -- decode -------------------------------------------------------------------------------
  * The parse + reconstruct half of AGMV_DecodeFrameChunk (reference src/agmv_decode.c:224-407)
  * for n_frames consecutive frames whose LZ stage (:171-222, host) has already run.
@@ -100,6 +133,12 @@ int agmv_hip_decode_frames_dev(agmv_hip_ctx* ctx, const uint8_t* d_bits, size_t 
                                uint32_t h, uint32_t first_frame_count, uint32_t* d_pix_out,
                                const uint32_t* d_prev_frame, const uint32_t* d_prev_iframe,
                                void* stream);
+/* After agmv_hip_decode_frames_dev: 1 when a pixel of that batch derives from d_prev_frame / d_prev_iframe (a block the
+   bitstream did not rewrite before it was read: stale tail after `escape`, COPY in the first GOP, a FILL / NORMAL block cut
+   off by bpos -- reference src/agmv_decode.c:229-232, :268-271, :277-285, :310-314), 0 when the batch is a function of its
+   own bitstreams alone, negative on error.  What a GOP-sharded decode needs to know before it trusts a range decoded from
+   the fresh state (never 1 for a stream the encoder emits).  Synchronises the stream. */
+int agmv_hip_decode_prior_dependent(agmv_hip_ctx* ctx, uint32_t w, uint32_t h, void* stream);
 /* host-memory convenience: parse on the GPU, reconstruct, copy back (synchronous) */
 int agmv_hip_decode_frames(agmv_hip_ctx* ctx, const uint8_t* h_bits, size_t bits_stride,
                            const uint32_t* h_bpos, uint32_t n_frames, uint32_t w, uint32_t h,

@@ -37,6 +37,18 @@ void agmv_die(const char* what)
 	abort();
 }
 
+/* the decoders have an error channel (enum Error): a GPU failure is reported on stderr AND returned, never papered over */
+static int gpu_failed(const char* what)
+{
+	fprintf(stderr, "libagmv(amd): %s: %s (the AGMV hot path runs on the GPU only -- no CPU fallback)\n", what, agmv_hip_last_error());
+	return MEMORY_CORRUPTION_ERR;
+}
+
+static int bad_geometry(uint32_t w, uint32_t h)
+{
+	return w == 0 || h == 0 || (w & 3u) || (h & 3u) || (unsigned long long)w * h > (1ull << 28);
+}
+
 void AGMV_SetBatchFrames(unsigned n) { g_batch_frames = n; }
 void AGMV_SetLZThreads(unsigned n) { g_lz_threads = n; }
 
@@ -227,6 +239,7 @@ int AGMV_DecodeFrameChunk(FILE* file, AGMV* a)
 	size_t i, cap, stride;
 	u8* slab;
 
+	if (bad_geometry(w, h)) return INVALID_HEADER_FORMATTING_ERR;      /* the block loops need multiples of 4 (src/agmv_decode.c:226-227) */
 	a->bitstream->pos = 0;
 	AGMV_ReadFourCC(file, a->frame_chunk->fourcc);
 	a->frame_chunk->frame_num = AGMV_ReadLong(file);
@@ -279,11 +292,14 @@ int AGMV_DecodeFrameChunk(FILE* file, AGMV* a)
 	use_palette(a->header.palette0, a->header.palette1, m512);
 	stride = ((size_t)bpos + 16 + 255) & ~(size_t)255;
 	slab = (u8*)calloc(stride, 1);
-	memcpy(slab, a->bitstream->data, (size_t)bpos + 16 <= cap ? (size_t)bpos + 16 : cap);   /* incl. the stale bytes */
 	prev = (uint32_t*)malloc(npx * 4); prev_i = (uint32_t*)malloc(npx * 4); out = (uint32_t*)malloc(npx * 4);
+	if (!slab || !prev || !prev_i || !out) { free(slab); free(prev); free(prev_i); free(out); return MEMORY_CORRUPTION_ERR; }
+	memcpy(slab, a->bitstream->data, (size_t)bpos + 16 <= cap ? (size_t)bpos + 16 : cap);   /* incl. the stale bytes */
 	for (i = 0; i < npx; i++) { prev[i] = (uint32_t)a->frame->img_data[i]; prev_i[i] = (uint32_t)a->iframe->img_data[i]; }
-	if (agmv_hip_decode_frames(ctx(), slab, stride, &bpos, 1, w, h, (uint32_t)a->frame_count, out, prev, prev_i))
-		agmv_die("AGMV_DecodeFrameChunk");
+	if (agmv_hip_decode_frames(ctx(), slab, stride, &bpos, 1, w, h, (uint32_t)a->frame_count, out, prev, prev_i)) {
+		free(slab); free(prev); free(prev_i); free(out);
+		return gpu_failed("AGMV_DecodeFrameChunk");
+	}
 	for (i = 0; i < npx; i++) a->frame->img_data[i] = out[i];
 	if (a->frame_count % 4 == 0) memcpy(a->iframe->img_data, a->frame->img_data, npx * sizeof(u32));   /* :401-405 */
 	a->frame_count++;
@@ -298,14 +314,13 @@ int AGMV_DecodeFrameChunk(FILE* file, AGMV* a)
  * ------------------------------------------------------------------------------------------ */
 static uint16_t gpu_entry_of(const u32* p0, const u32* p1, int m512, u32 color)
 {
-	uint32_t px = (uint32_t)color, *d_px;
-	uint16_t e = 0, *d_e;
-	use_palette(p0, p1, m512);
-	d_px = (uint32_t*)agmv_hip_malloc(4); d_e = (uint16_t*)agmv_hip_malloc(2);
-	if (!d_px || !d_e || agmv_hip_memcpy_h2d(d_px, &px, 4) || agmv_hip_quantise_dev(g_ctx, d_px, 1, d_e, NULL) ||
-	    agmv_hip_memcpy_d2h(&e, d_e, 2))
-		agmv_die("nearest entry");
-	agmv_hip_free(d_px); agmv_hip_free(d_e);
+	/* the reference's own search, run on the GPU against the caller's palettes (no table is built for a single
+	   colour; the device scratch lives in the context): src/agmv_utils.c:785-816, :851-895 */
+	uint32_t pal[512], px = (uint32_t)color;
+	uint16_t e = 0;
+	int i;
+	for (i = 0; i < 256; i++) { pal[i] = (uint32_t)p0[i]; pal[256 + i] = m512 ? (uint32_t)p1[i] : 0; }
+	if (agmv_hip_nearest(ctx(), pal, pal + 256, m512, &px, 1, &e)) agmv_die("nearest entry");
 	return e;
 }
 
@@ -322,59 +337,62 @@ AGMV_ENTRY AGMV_FindNearestEntry(u32 palette0[256], u32 palette1[256], u32 color
 
 static u32 entry_colour(AGMV* a, const AGMV_ENTRY* e) { return e->pal_num ? a->header.palette1[e->index] : a->header.palette0[e->index]; }
 
-/* the two block predicates are pure table look-ups on 16 entries; they are evaluated by re-encoding the
-   frame on the GPU when used through AGMV_Assemble*; standalone calls (no caller in the reference besides
-   the assemblers) evaluate the +-2 window directly on the palette colours of the given entries. */
-static int within2(u32 c1, u32 c2)
+/* the two block predicates (reference src/agmv_encode.c:302-352, :240-300): the 16 palette colours of the block and the
+   16 colours they are compared with go to the GPU, which counts the pairs within +-2 on every channel */
+static u8 count_within2(const uint32_t* a, const uint32_t* b)
 {
-	int dr = (int)AGMV_GetR(c1) - AGMV_GetR(c2), dg = (int)AGMV_GetG(c1) - AGMV_GetG(c2), db = (int)AGMV_GetB(c1) - AGMV_GetB(c2);
-	return abs(dr) <= 2 && abs(dg) <= 2 && abs(db) <= 2;
+	int n = agmv_hip_within2_count(ctx(), a, b);
+	if (n < 0) agmv_die("block compare");
+	return (u8)n;
 }
 
 u8 AGMV_CompareIFrameBlock(AGMV* a, u32 x, u32 y, u32 color, AGMV_ENTRY* e)
 {
 	u32 w = a->frame->width, i, j;
-	u8 n = 0;
-	for (j = 0; j < 4; j++) for (i = 0; i < 4; i++) n += (u8)within2(color, entry_colour(a, &e[(x + i) + (y + j) * w]));
-	return n;
+	uint32_t ca[16], cb[16];
+	for (j = 0; j < 4; j++) for (i = 0; i < 4; i++) { ca[j * 4 + i] = (uint32_t)entry_colour(a, &e[(x + i) + (y + j) * w]); cb[j * 4 + i] = (uint32_t)color; }
+	return count_within2(ca, cb);
 }
 
 u8 AGMV_ComparePFrameBlock(AGMV* a, u32 x, u32 y, AGMV_ENTRY* e)
 {
 	u32 w = a->frame->width, i, j;
-	u8 n = 0;
+	uint32_t ca[16], cb[16];
 	for (j = 0; j < 4; j++)
 		for (i = 0; i < 4; i++) {
 			size_t k = (x + i) + (size_t)(y + j) * w;
-			n += (u8)within2(entry_colour(a, &e[k]), entry_colour(a, &a->iframe_entries[k]));
+			ca[j * 4 + i] = (uint32_t)entry_colour(a, &e[k]);
+			cb[j * 4 + i] = (uint32_t)entry_colour(a, &a->iframe_entries[k]);
 		}
-	return n;
+	return count_within2(ca, cb);
 }
 
-/* entries -> bitstream: feed the GPU encoder the palette COLOURS of the entries (a palette colour
-   quantises to an entry with the identical colour, so classification and codes are those of the
-   given plane whenever the palette has no duplicate colours ahead of the entry) */
+/* entries -> bitstream on the GPU: the entry plane goes to the encoder AS ENTRIES (agmv_hip_encode_entries: no
+   quantisation), so classification and codes are exactly those of the given plane -- also for palettes with duplicate
+   colours, where re-quantising an entry's colour would return the first of the duplicates
+   (reference src/agmv_encode.c:354-436, :438-527; bytes are appended at bitstream->pos like the reference does) */
 static void assemble_via_gpu(AGMV* a, AGMV_ENTRY* e, int iframe)
 {
 	const uint32_t w = (uint32_t)a->frame->width, h = (uint32_t)a->frame->height;
+	const int m512 = mode512_of(AGMV_GetOPT(a));
 	const size_t npx = (size_t)w * h, stride = agmv_hip_max_usize(w, h, 1);
-	uint32_t* pix = (uint32_t*)malloc(npx * 4), usize = 0;
+	uint32_t* ent = (uint32_t*)malloc(npx * 4), usize = 0;
 	uint16_t* ient = (uint16_t*)malloc(npx * 2);
 	u8* bytes = (u8*)malloc(stride);
 	size_t i;
-	use_palette(a->header.palette0, a->header.palette1, mode512_of(AGMV_GetOPT(a)));
+	use_palette(a->header.palette0, a->header.palette1, m512);
 	for (i = 0; i < npx; i++) {
-		pix[i] = (uint32_t)entry_colour(a, &e[i]);
-		ient[i] = (uint16_t)(a->iframe_entries[i].pal_num << 8 | a->iframe_entries[i].index);
+		ent[i] = m512 ? (uint32_t)((e[i].pal_num & 1u) << 8 | e[i].index) : (uint32_t)e[i].index;
+		ient[i] = (uint16_t)((a->iframe_entries[i].pal_num & 1u) << 8 | a->iframe_entries[i].index);
 	}
-	if (agmv_hip_encode_frames(ctx(), pix, 1, w, h, iframe ? 0u : 1u, bytes, stride, &usize, ient)) agmv_die("AGMV_Assemble*FrameBitstream");
+	if (agmv_hip_encode_entries(ctx(), ent, 1, w, h, iframe ? 0u : 1u, bytes, stride, &usize, ient)) agmv_die("AGMV_Assemble*FrameBitstream");
 	if ((size_t)a->bitstream->pos + usize > a->bitstream->len) {
 		a->bitstream->len = a->bitstream->pos + usize + 64;
 		a->bitstream->data = (u8*)realloc(a->bitstream->data, a->bitstream->len);
 	}
 	memcpy(a->bitstream->data + a->bitstream->pos, bytes, usize);
 	a->bitstream->pos += usize;
-	free(pix); free(ient); free(bytes);
+	free(ent); free(ient); free(bytes);
 }
 
 void AGMV_AssembleIFrameBitstream(AGMV* a, AGMV_ENTRY* e) { assemble_via_gpu(a, e, 1); }

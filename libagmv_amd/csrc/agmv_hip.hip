@@ -124,6 +124,13 @@ struct agmv_hip_ctx {
 	int timing;                     // record HIP events around the three hot kernels
 	hipEvent_t ev[6];               // encode, parse, decode: start/stop
 	size_t parse_ws_cap;            // in dwords
+	hipEvent_t ev_enc;              // end of the last encode launch (encodes of one context share status / control words)
+	hipStream_t enc_stream;         // ... and the stream it went to
+	int have_enc;
+	uint32_t* d_nn_pal;             // agmv_hip_nearest: palette, pixels, entries (grown on demand)
+	uint32_t* d_nn_pix;
+	uint16_t* d_nn_ent;
+	size_t nn_cap;
 };
 
 extern "C" size_t agmv_hip_max_usize(uint32_t w, uint32_t h, int mode512)
@@ -378,7 +385,7 @@ __device__ __forceinline__ uint32_t lds_wait(const uint32_t* p, uint32_t tag, in
 	unsigned spins = 0;
 	while ((v >> shift) != tag) {
 		__builtin_amdgcn_s_sleep(1);
-		if (++spins > (1u << 20)) {                          // ~0.1 s; a legitimate wait is microseconds
+		if (++spins > (1u << 24)) {                          // a legitimate wait is microseconds; the bound is above the look-back's (1 << 22 polls of global memory), which this wait can transitively wait for
 			if (lane == 0) atomicExch(ctrl + 1, 2u);
 			break;
 		}
@@ -449,7 +456,10 @@ struct EncGeo {
 	bool valid;
 };
 
-template <bool M512>
+// ENTRIES: the input planes hold ENTRIES (one per 32-bit word, pal_num << 8 | index) instead of pixels -- the table look-ups
+// are skipped and classification + emission run on the caller's entries (AGMV_AssembleIFrameBitstream /
+// AGMV_AssemblePFrameBitstream on a given AGMV_ENTRY plane, src/agmv_encode.c:354-527).
+template <bool M512, bool ENTRIES>
 __global__ __launch_bounds__(ENC_T, ENC_WPE) ENC_WAVES_ATTR void k_encode(EncArgs A)
 {
 	constexpr int NROWS = M512 ? 512 : 256;
@@ -718,7 +728,8 @@ __global__ __launch_bounds__(ENC_T, ENC_WPE) ENC_WAVES_ATTR void k_encode(EncArg
 #ifdef ABL_NOGATHER
 			eq[k] = pxv[k] & 0x1FFu;
 #else
-			eq[k] = (uint16_t)__builtin_amdgcn_raw_buffer_load_b16(lut_rs, LUT_OFF(pxv[k]), 0, ENC_LUTAUX);
+			if (ENTRIES) eq[k] = pxv[k] & (M512 ? 0x1FFu : 0xFFu);
+			else eq[k] = (uint16_t)__builtin_amdgcn_raw_buffer_load_b16(lut_rs, LUT_OFF(pxv[k]), 0, ENC_LUTAUX);
 #endif
 		}
 #endif
@@ -1496,6 +1507,9 @@ __global__ __launch_bounds__(DEC_T, DEC_WPE) void k_decode(DecArgs A)
 	}
 	uint32_t cur[16], icol[16];
 	bool stale, istale;
+	// stale / istale: the block's img_data / iframe->img_data still derive from the state before this GOP.  For the first
+	// GOP of the batch that state is the caller's (prev / prev_iframe) and the pixels are right as they are; what the
+	// flags then tell is whether the batch DEPENDS on the state handed in (reported through agmv_hip_decode_prior_dependent).
 	if (group == 0) {                                          // state of the decoder before the batch
 		if (A.prev) load_block(A.prev, poff, A.w, cur);
 		else {
@@ -1507,12 +1521,11 @@ __global__ __launch_bounds__(DEC_T, DEC_WPE) void k_decode(DecArgs A)
 #pragma unroll
 			for (int k = 0; k < 16; k++) icol[k] = 0;
 		}
-		stale = false; istale = false;
 	} else {
 #pragma unroll
 		for (int k = 0; k < 16; k++) { cur[k] = 0; icol[k] = 0; }
-		stale = true; istale = true;
 	}
+	stale = true; istale = true;
 	// the range the tile's entered blocks can touch in frame i: [first entry, last entry + 33 + 8]; entry offsets
 	// increase with the block index, so it is [offset of lane 0, offset of the last entered lane]
 #pragma unroll
@@ -1557,7 +1570,7 @@ __global__ __launch_bounds__(DEC_T, DEC_WPE) void k_decode(DecArgs A)
 	}
 	__syncthreads();                                           // the last wait on global loads in this kernel
 
-	bool anystale = false;
+	bool anystale = false, needfix = false;
 #pragma unroll
 	for (int i = 0; i < 4; i++) {
 		if (i >= nf) break;
@@ -1585,7 +1598,7 @@ __global__ __launch_bounds__(DEC_T, DEC_WPE) void k_decode(DecArgs A)
 					for (int k = 0; k < 16; k++) cur[k] = c;
 					stale = s_nbstale[tid - 1] != 0;
 				} else {
-					stale = true;                              // neighbour lives in another tile: fix-up
+					stale = true; needfix = true;             // neighbour lives in another tile: fix-up (the pixels here are NOT final)
 				}
 			}
 			lds_barrier();
@@ -1598,9 +1611,12 @@ __global__ __launch_bounds__(DEC_T, DEC_WPE) void k_decode(DecArgs A)
 		anystale |= stale;
 		if (valid) store_block(A.out + (size_t)f * npx, poff, A.w, cur);
 	}
-	if (valid && anystale) {                                   // stale in any frame of the GOP: k_fixup replays the block
-		atomicOr(A.dirty + (blk >> 5), 1u << (blk & 31u));
-		A.dirty[(A.nblk + 31) >> 5] = 1u;                       // "anything to repair" word behind the bitmap
+	if (valid && (anystale || needfix)) {
+		if (group != 0 || needfix) {                           // stale in any frame of a later GOP: k_fixup replays the block
+			atomicOr(A.dirty + (blk >> 5), 1u << (blk & 31u));
+			A.dirty[(A.nblk + 31) >> 5] = 1u;                   // "anything to repair" word behind the bitmap
+		}
+		if (group == 0 && anystale) A.dirty[((A.nblk + 31) >> 5) + 1] = 1u;   // the batch depends on the decoder state before it
 	}
 }
 
@@ -1780,6 +1796,46 @@ __global__ __launch_bounds__(256) void k_histogram(const uint32_t* __restrict__ 
 	}
 }
 
+// A spin of k_encode that ran into its bound leaves ctrl[1] != 0 and the kernel carries on with a wrong offset: the bytes of
+// the batch are not to be used.  So that a caller who skips agmv_hip_check cannot take them for good ones, every size of
+// the batch is then overwritten with 0xFFFFFFFF (no frame is that long: agmv_hip_max_usize < 2^32).
+__global__ __launch_bounds__(64) void k_encode_verdict(const uint32_t* __restrict__ ctrl, uint32_t* __restrict__ sizes, uint32_t n_frames)
+{
+	if (ctrl[1] == 0) return;
+	for (uint32_t f = threadIdx.x; f < n_frames; f += 64) sizes[f] = 0xFFFFFFFFu;
+}
+
+// E2 / E3 without the table: nearest colour / entry of n pixels by the reference's own search (src/agmv_utils.c:785-895).
+// For the exported single-colour functions AGMV_FindNearestColor / AGMV_FindNearestEntry, whose palette argument changes from
+// call to call: building a 2^24-entry table for one look-up would cost 2 ms.
+__global__ __launch_bounds__(64) void k_nearest_direct(const uint32_t* __restrict__ pal, int mode512, const uint32_t* __restrict__ pix,
+                                                       size_t n, uint16_t* __restrict__ out)
+{
+	const size_t i = (size_t)blockIdx.x * 64 + threadIdx.x;
+	if (i >= n) return;
+	const uint32_t c = pix[i];
+	const int r = (int)((c >> 16) & 0xff), g = (int)((c >> 8) & 0xff), b = (int)(c & 0xff);
+	uint32_t d0, i0;
+	nearest_in(pal, r, g, b, d0, i0);
+	uint32_t e = i0;
+	if (mode512) {
+		uint32_t d1, i1;
+		nearest_in(pal + 256, r, g, b, d1, i1);
+		if (!(d0 <= d1)) e = 0x100u | i1;
+	}
+	out[i] = (uint16_t)e;
+}
+
+// E5 / E6 on 16 colour pairs: how many pairs are within +-2 on R, G and B (the predicate of AGMV_CompareIFrameBlock /
+// AGMV_ComparePFrameBlock, src/agmv_encode.c:293, :345), for the exported single-block helpers.
+__global__ __launch_bounds__(64) void k_within2_count(const uint32_t* __restrict__ ab, uint32_t* __restrict__ out)
+{
+	const int lane = threadIdx.x;
+	const bool in = lane < 16 && within2(ab[lane], ab[16 + lane]);
+	const unsigned long long m = __ballot(in);
+	if (lane == 0) out[0] = (uint32_t)__popcll(m);
+}
+
 // ----------------------------------------------------------------------------------------------
 // C-ABI
 // ----------------------------------------------------------------------------------------------
@@ -1817,8 +1873,8 @@ extern "C" agmv_hip_ctx* agmv_hip_create(int device)
 	{
 		int per_cu = 0;
 		const size_t lds = (size_t)512 * MROW * 4 + ENC_LDS_EXTRA;
-		(void)hipFuncSetAttribute((const void*)k_encode<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-		if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)k_encode<true>, ENC_T, lds) != hipSuccess || per_cu < 1) per_cu = 2;
+		(void)hipFuncSetAttribute((const void*)k_encode<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+		if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)k_encode<true, false>, ENC_T, lds) != hipSuccess || per_cu < 1) per_cu = 2;
 		if (getenv("AGMV_HIP_DEBUG")) fprintf(stderr, "agmv_hip: k_encode: %d workgroup(s) of %d lanes resident per CU (%zu B of LDS each), %d CUs\n", per_cu, ENC_T, lds, c->n_cu);
 		c->enc_grid = prop.multiProcessorCount * per_cu;
 	}
@@ -1831,6 +1887,9 @@ extern "C" void agmv_hip_destroy(agmv_hip_ctx* c)
 	(void)hipSetDevice(c->device);
 	(void)hipFree(c->d_lut); (void)hipFree(c->d_mtx); (void)hipFree(c->d_pal); (void)hipFree(c->d_ctrl);
 	(void)hipFree(c->d_status); (void)hipFree(c->d_dirty); (void)hipFree(c->d_parse_ws); (void)hipFree(c->d_ient_tmp);
+	(void)hipFree(c->d_nn_pal); (void)hipFree(c->d_nn_pix); (void)hipFree(c->d_nn_ent);
+	if (c->ev_enc) (void)hipEventDestroy(c->ev_enc);
+	for (int i = 0; i < 6; i++) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
 	free(c);
 }
 
@@ -1907,9 +1966,9 @@ static int check_geometry(uint32_t w, uint32_t h)
 	return 0;
 }
 
-extern "C" int agmv_hip_encode_frames_dev(agmv_hip_ctx* c, const uint32_t* d_pix, uint32_t n_frames, uint32_t w, uint32_t h,
-                                          uint32_t first_fc, uint8_t* d_out, size_t out_stride, uint32_t* d_sizes,
-                                          uint16_t* d_ientries, void* stream)
+static int encode_dev(agmv_hip_ctx* c, const uint32_t* d_pix, uint32_t n_frames, uint32_t w, uint32_t h,
+                      uint32_t first_fc, uint8_t* d_out, size_t out_stride, uint32_t* d_sizes,
+                      uint16_t* d_ientries, void* stream, bool entries)
 {
 	if (need_ctx(c, true)) return -1;
 	if (check_geometry(w, h)) return -1;
@@ -1958,20 +2017,41 @@ extern "C" int agmv_hip_encode_frames_dev(agmv_hip_ctx* c, const uint32_t* d_pix
 		}
 		A.ientries_out = c->d_ient_tmp;
 	}
+	// the look-back status and the control words belong to the context: an encode on another stream waits for the previous one
+	if (!c->ev_enc) CK(hipEventCreateWithFlags(&c->ev_enc, hipEventDisableTiming));
+	if (c->have_enc && c->enc_stream != s) CK(hipStreamWaitEvent(s, c->ev_enc, 0));
 	CK(hipMemsetAsync(c->d_status, 0, need * sizeof(unsigned long long), s));
 	CK(hipMemsetAsync(c->d_ctrl, 0, CTRL_BYTES, s));
 	uint32_t grid = (uint32_t)c->enc_grid;
 	if (grid > A.total_tiles) grid = A.total_tiles;
 	const size_t lds = (size_t)(c->mode512 ? 512 : 256) * MROW * 4 + ENC_LDS_EXTRA;
-	if (c->mode512) CK(hipFuncSetAttribute((const void*)k_encode<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-	else CK(hipFuncSetAttribute((const void*)k_encode<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+	void (*kern)(EncArgs) = c->mode512 ? (entries ? k_encode<true, true> : k_encode<true, false>)
+	                                   : (entries ? k_encode<false, true> : k_encode<false, false>);
+	CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
 	ev_mark(c, 0, s);
-	if (c->mode512) hipLaunchKernelGGL(k_encode<true>, dim3(grid), dim3(ENC_T), lds, s, A);
-	else hipLaunchKernelGGL(k_encode<false>, dim3(grid), dim3(ENC_T), lds, s, A);
+	hipLaunchKernelGGL(kern, dim3(grid), dim3(ENC_T), lds, s, A);
 	ev_mark(c, 1, s);
 	CK(hipGetLastError());
+	hipLaunchKernelGGL(k_encode_verdict, dim3(1), dim3(64), 0, s, c->d_ctrl, d_sizes, n_frames);
+	CK(hipGetLastError());
 	if (ient_both) CK(hipMemcpyAsync(d_ientries, c->d_ient_tmp, npx_e * sizeof(uint16_t), hipMemcpyDeviceToDevice, s));
+	CK(hipEventRecord(c->ev_enc, s));
+	c->enc_stream = s; c->have_enc = 1;
 	return 0;
+}
+
+extern "C" int agmv_hip_encode_frames_dev(agmv_hip_ctx* c, const uint32_t* d_pix, uint32_t n_frames, uint32_t w, uint32_t h,
+                                          uint32_t first_fc, uint8_t* d_out, size_t out_stride, uint32_t* d_sizes,
+                                          uint16_t* d_ientries, void* stream)
+{
+	return encode_dev(c, d_pix, n_frames, w, h, first_fc, d_out, out_stride, d_sizes, d_ientries, stream, false);
+}
+
+extern "C" int agmv_hip_encode_entries_dev(agmv_hip_ctx* c, const uint32_t* d_entries, uint32_t n_frames, uint32_t w, uint32_t h,
+                                           uint32_t first_fc, uint8_t* d_out, size_t out_stride, uint32_t* d_sizes,
+                                           uint16_t* d_ientries, void* stream)
+{
+	return encode_dev(c, d_entries, n_frames, w, h, first_fc, d_out, out_stride, d_sizes, d_ientries, stream, true);
 }
 
 extern "C" int agmv_hip_check(agmv_hip_ctx* c, void* stream)
@@ -1997,8 +2077,8 @@ extern "C" int agmv_hip_check(agmv_hip_ctx* c, void* stream)
 	return 0;
 }
 
-extern "C" int agmv_hip_encode_frames(agmv_hip_ctx* c, const uint32_t* h_pix, uint32_t n_frames, uint32_t w, uint32_t h,
-                                      uint32_t first_fc, uint8_t* h_out, size_t out_stride, uint32_t* h_sizes, uint16_t* h_ient)
+static int encode_host(agmv_hip_ctx* c, const uint32_t* h_pix, uint32_t n_frames, uint32_t w, uint32_t h,
+                       uint32_t first_fc, uint8_t* h_out, size_t out_stride, uint32_t* h_sizes, uint16_t* h_ient, bool entries)
 {
 	if (need_ctx(c, true)) return -1;
 	if (check_geometry(w, h)) return -1;
@@ -2015,7 +2095,7 @@ extern "C" int agmv_hip_encode_frames(agmv_hip_ctx* c, const uint32_t* h_pix, ui
 		}
 		if (hipMemcpy(d_pix, h_pix, npx * 4 * n_frames, hipMemcpyHostToDevice) != hipSuccess) { snprintf(g_err, sizeof(g_err), "agmv_hip: H2D failed"); break; }
 		if (h_ient && hipMemcpy(d_ient, h_ient, npx * 2, hipMemcpyHostToDevice) != hipSuccess) { snprintf(g_err, sizeof(g_err), "agmv_hip: H2D failed"); break; }
-		if (agmv_hip_encode_frames_dev(c, d_pix, n_frames, w, h, first_fc, d_out, out_stride, d_sizes, d_ient, nullptr)) break;
+		if (encode_dev(c, d_pix, n_frames, w, h, first_fc, d_out, out_stride, d_sizes, d_ient, nullptr, entries)) break;
 		if (agmv_hip_check(c, nullptr)) break;
 		if (hipMemcpy(h_sizes, d_sizes, 4 * (size_t)n_frames, hipMemcpyDeviceToHost) != hipSuccess) { snprintf(g_err, sizeof(g_err), "agmv_hip: D2H failed"); break; }
 		bool ok = true;
@@ -2027,6 +2107,56 @@ extern "C" int agmv_hip_encode_frames(agmv_hip_ctx* c, const uint32_t* h_pix, ui
 	} while (0);
 	(void)hipFree(d_pix); (void)hipFree(d_out); (void)hipFree(d_sizes); (void)hipFree(d_ient);
 	return rc;
+}
+
+extern "C" int agmv_hip_encode_frames(agmv_hip_ctx* c, const uint32_t* h_pix, uint32_t n_frames, uint32_t w, uint32_t h,
+                                      uint32_t first_fc, uint8_t* h_out, size_t out_stride, uint32_t* h_sizes, uint16_t* h_ient)
+{
+	return encode_host(c, h_pix, n_frames, w, h, first_fc, h_out, out_stride, h_sizes, h_ient, false);
+}
+
+extern "C" int agmv_hip_encode_entries(agmv_hip_ctx* c, const uint32_t* h_entries, uint32_t n_frames, uint32_t w, uint32_t h,
+                                       uint32_t first_fc, uint8_t* h_out, size_t out_stride, uint32_t* h_sizes, uint16_t* h_ient)
+{
+	return encode_host(c, h_entries, n_frames, w, h, first_fc, h_out, out_stride, h_sizes, h_ient, true);
+}
+
+extern "C" int agmv_hip_within2_count(agmv_hip_ctx* c, const uint32_t a[16], const uint32_t b[16])
+{
+	if (need_ctx(c, false)) return -1;
+	if (!c->d_nn_pal) CK(hipMalloc(&c->d_nn_pal, 512 * sizeof(uint32_t)));
+	uint32_t ab[32], n = 0;
+	memcpy(ab, a, 64); memcpy(ab + 16, b, 64);
+	CK(hipMemcpy(c->d_nn_pal, ab, sizeof(ab), hipMemcpyHostToDevice));
+	hipLaunchKernelGGL(k_within2_count, dim3(1), dim3(64), 0, nullptr, c->d_nn_pal, c->d_nn_pal + 32);
+	CK(hipGetLastError());
+	CK(hipMemcpy(&n, c->d_nn_pal + 32, 4, hipMemcpyDeviceToHost));
+	return (int)n;
+}
+
+extern "C" int agmv_hip_nearest(agmv_hip_ctx* c, const uint32_t p0[256], const uint32_t p1[256], int mode512,
+                                const uint32_t* h_pix, size_t n, uint16_t* h_entries)
+{
+	if (need_ctx(c, false)) return -1;
+	if (n == 0) return 0;
+	if (!c->d_nn_pal) CK(hipMalloc(&c->d_nn_pal, 512 * sizeof(uint32_t)));
+	if (n > c->nn_cap) {
+		(void)hipFree(c->d_nn_pix); (void)hipFree(c->d_nn_ent);
+		c->d_nn_pix = nullptr; c->d_nn_ent = nullptr; c->nn_cap = 0;
+		const size_t cap = n < 256 ? 256 : n;
+		CK(hipMalloc(&c->d_nn_pix, cap * sizeof(uint32_t)));
+		CK(hipMalloc(&c->d_nn_ent, cap * sizeof(uint16_t)));
+		c->nn_cap = cap;
+	}
+	uint32_t pal[512];
+	memcpy(pal, p0, 1024);
+	if (mode512 && p1) memcpy(pal + 256, p1, 1024); else memset(pal + 256, 0, 1024);
+	CK(hipMemcpy(c->d_nn_pal, pal, sizeof(pal), hipMemcpyHostToDevice));
+	CK(hipMemcpy(c->d_nn_pix, h_pix, n * sizeof(uint32_t), hipMemcpyHostToDevice));
+	hipLaunchKernelGGL(k_nearest_direct, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, nullptr, c->d_nn_pal, mode512 ? 1 : 0, c->d_nn_pix, n, c->d_nn_ent);
+	CK(hipGetLastError());
+	CK(hipMemcpy(h_entries, c->d_nn_ent, n * sizeof(uint16_t), hipMemcpyDeviceToHost));
+	return 0;
 }
 
 extern "C" int agmv_hip_parse_frames_dev(agmv_hip_ctx* c, const uint8_t* d_bits, size_t stride, const uint32_t* d_bpos,
@@ -2105,7 +2235,7 @@ extern "C" int agmv_hip_decode_frames_dev(agmv_hip_ctx* c, const uint8_t* d_bits
 	A.tpf = (A.nblk + DEC_T - 1) / DEC_T;
 	A.first_fc = first_fc; A.phase = first_fc & 3u;
 	A.n_groups = (n_frames + A.phase + 3) / 4;
-	size_t nwords = (A.nblk + 31) / 32 + 1;                    // bitmap + the "anything to repair" word
+	size_t nwords = (A.nblk + 31) / 32 + 2;                    // bitmap + the "anything to repair" word + the "depends on the prior state" word
 	if (nwords > c->dirty_cap) {
 		if (c->d_dirty) CK(hipFree(c->d_dirty));
 		c->d_dirty = nullptr; c->dirty_cap = 0;
@@ -2127,6 +2257,17 @@ extern "C" int agmv_hip_decode_frames_dev(agmv_hip_ctx* c, const uint8_t* d_bits
 	CK(hipGetLastError());
 	ev_mark(c, 5, s);
 	return 0;
+}
+
+extern "C" int agmv_hip_decode_prior_dependent(agmv_hip_ctx* c, uint32_t w, uint32_t h, void* stream)
+{
+	if (need_ctx(c, false)) return -1;
+	if (!c->d_dirty) { snprintf(g_err, sizeof(g_err), "agmv_hip: no decode has run on this context"); return -1; }
+	const size_t nblk = (size_t)(w / 4) * (h / 4);
+	uint32_t v = 0;
+	CK(hipStreamSynchronize((hipStream_t)stream));
+	CK(hipMemcpy(&v, c->d_dirty + (nblk + 31) / 32 + 1, 4, hipMemcpyDeviceToHost));
+	return v ? 1 : 0;
 }
 
 extern "C" int agmv_hip_decode_frames(agmv_hip_ctx* c, const uint8_t* h_bits, size_t stride, const uint32_t* h_bpos,

@@ -15,8 +15,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ABI_SYMBOLS = [
     "agmv_hip_max_usize", "agmv_hip_device_count", "agmv_hip_create", "agmv_hip_destroy",
     "agmv_hip_last_error", "agmv_hip_set_palette", "agmv_hip_quantise_dev",
-    "agmv_hip_encode_frames_dev", "agmv_hip_encode_frames", "agmv_hip_parse_frames_dev",
-    "agmv_hip_decode_frames_dev", "agmv_hip_decode_frames", "agmv_hip_synth_dev",
+    "agmv_hip_encode_frames_dev", "agmv_hip_encode_frames", "agmv_hip_encode_entries_dev",
+    "agmv_hip_encode_entries", "agmv_hip_nearest", "agmv_hip_within2_count", "agmv_hip_parse_frames_dev",
+    "agmv_hip_decode_frames_dev", "agmv_hip_decode_frames", "agmv_hip_decode_prior_dependent", "agmv_hip_synth_dev",
     "agmv_hip_interp_dev", "agmv_hip_histogram_dev", "agmv_hip_check", "agmv_hip_malloc",
     "agmv_hip_free", "agmv_hip_memcpy_h2d", "agmv_hip_memcpy_d2h", "agmv_hip_memset",
     "agmv_hip_sync", "agmv_hip_enable_timing", "agmv_hip_last_kernel_ms",
@@ -60,9 +61,16 @@ def load_library(path=None):
     L.agmv_hip_quantise_dev.argtypes = [vp, vp, sz, vp, vp]
     L.agmv_hip_encode_frames_dev.argtypes = [vp, vp, u32, u32, u32, u32, vp, sz, vp, vp, vp]
     L.agmv_hip_encode_frames.argtypes = [vp, vp, u32, u32, u32, u32, vp, sz, vp, vp]
+    L.agmv_hip_encode_entries_dev.argtypes = [vp, vp, u32, u32, u32, u32, vp, sz, vp, vp, vp]
+    L.agmv_hip_encode_entries.argtypes = [vp, vp, u32, u32, u32, u32, vp, sz, vp, vp]
+    L.agmv_hip_nearest.argtypes = [vp, vp, vp, C.c_int, vp, sz, vp]
+    L.agmv_hip_within2_count.argtypes = [vp, vp, vp]
+    L.agmv_hip_within2_count.restype = C.c_int
     L.agmv_hip_parse_frames_dev.argtypes = [vp, vp, sz, vp, u32, u32, u32, vp, vp, vp]
     L.agmv_hip_decode_frames_dev.argtypes = [vp, vp, sz, vp, vp, vp, u32, u32, u32, u32, vp, vp, vp, vp]
     L.agmv_hip_decode_frames.argtypes = [vp, vp, sz, vp, u32, u32, u32, u32, vp, vp, vp]
+    L.agmv_hip_decode_prior_dependent.argtypes = [vp, u32, u32, vp]
+    L.agmv_hip_decode_prior_dependent.restype = C.c_int
     L.agmv_hip_synth_dev.argtypes = [vp, vp, u32, u32, u32, u32, C.c_uint64, vp]
     L.agmv_hip_interp_dev.argtypes = [vp, vp, vp, vp, sz, vp]
     L.agmv_hip_histogram_dev.argtypes = [vp, vp, sz, C.c_int, vp, vp]
@@ -75,7 +83,7 @@ def load_library(path=None):
     L.agmv_hip_malloc.argtypes = [sz]
     L.agmv_hip_free.argtypes = [vp]
     for f in (L.agmv_hip_set_palette, L.agmv_hip_quantise_dev, L.agmv_hip_encode_frames_dev,
-              L.agmv_hip_encode_frames, L.agmv_hip_parse_frames_dev, L.agmv_hip_decode_frames_dev,
+              L.agmv_hip_encode_frames, L.agmv_hip_encode_entries_dev, L.agmv_hip_encode_entries, L.agmv_hip_nearest, L.agmv_hip_parse_frames_dev, L.agmv_hip_decode_frames_dev,
               L.agmv_hip_decode_frames, L.agmv_hip_synth_dev, L.agmv_hip_interp_dev,
               L.agmv_hip_histogram_dev, L.agmv_hip_check):
         f.restype = C.c_int
@@ -155,6 +163,26 @@ class AgmvHip:
             sizes.data_ptr(), ientries.data_ptr() if ientries is not None else None, self._stream()))
         return out, sizes
 
+    def encode_entries_host(self, entries, first_frame_count=0, ientries=None):
+        """entries: uint32 ndarray [n, h, w] of pal_num << 8 | index. Returns the per-frame bitstreams."""
+        entries = np.ascontiguousarray(entries, np.uint32)
+        n, h, w = entries.shape
+        stride = self.max_usize(w, h)
+        out = np.zeros((n, stride), np.uint8)
+        sizes = np.zeros(n, np.uint32)
+        self._ck(self.L.agmv_hip_encode_entries(self.ctx, _np_ptr(entries), n, w, h, first_frame_count,
+                                                _np_ptr(out), stride, _np_ptr(sizes), _np_ptr(ientries)))
+        return [out[i, :sizes[i]].copy() for i in range(n)]
+
+    def nearest_host(self, p0, p1, pix, mode512=True):
+        """exact nearest entries of `pix` against (p0, p1) without building a table"""
+        p0 = np.ascontiguousarray(p0, np.uint32)
+        p1 = np.ascontiguousarray(p1 if p1 is not None else np.zeros(256), np.uint32)
+        pix = np.ascontiguousarray(pix, np.uint32).reshape(-1)
+        out = np.zeros(pix.size, np.uint16)
+        self._ck(self.L.agmv_hip_nearest(self.ctx, _np_ptr(p0), _np_ptr(p1), int(mode512), _np_ptr(pix), pix.size, _np_ptr(out)))
+        return out
+
     def parse_dev(self, bits, bpos, n_frames, w, h, offsets=None, nentered=None):
         import torch
         nblk = (w // 4) * (h // 4)
@@ -178,6 +206,13 @@ class AgmvHip:
             prev.data_ptr() if prev is not None else None,
             prev_iframe.data_ptr() if prev_iframe is not None else None, self._stream()))
         return out
+
+    def decode_depends_on_prior(self, w, h):
+        """after decode_dev: does any pixel of that batch derive from prev / prev_iframe (see agmv_hip.h)?"""
+        rc = self.L.agmv_hip_decode_prior_dependent(self.ctx, w, h, self._stream())
+        if rc < 0:
+            raise RuntimeError(self.L.agmv_hip_last_error().decode())
+        return bool(rc)
 
     def synth_dev(self, w, h, t0, n_frames, seed=0xA6D5, out=None, device=None):
         import torch

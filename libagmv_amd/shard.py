@@ -85,15 +85,42 @@ def split_packed(sizes, packed):
 
 COPY_FLAG = 0x5E            # include/agmv_defines.h:51
 NORMAL_FLAG = 0x2F          # :50
+FILL_FLAG = 0x4E            # :49
+
+
+def _block_end(row, start, bpos, mode512):
+    """one block of the reference's loop (src/agmv_decode.c:234-319 / :335-396) entered at byte `start` of the frame `row`
+    (numpy uint8): returns (flag, end) with the flag the block is decoded under -- the first flag-valued byte at or after the
+    entry position (the resync of :236-243) -- and the position behind its last byte; flag None when the resync runs off the
+    stream (the block is then not written)."""
+    n = len(row)
+    p = start
+    while p < n and row[p] not in (FILL_FLAG, NORMAL_FLAG, COPY_FLAG):
+        p += 1
+        if p >= bpos:                                         # the byte read at p makes bitpos = p + 1 > bpos: escape
+            return None, p
+    if p >= n:
+        return None, p
+    flag = int(row[p])
+    pos = p + 1
+    if flag == FILL_FLAG:
+        pos += 2 if (mode512 and pos < n and (row[pos] & 0x7f) == 127) else 1
+    elif flag == NORMAL_FLAG:
+        for _ in range(16):
+            pos += 2 if (mode512 and pos < n and (row[pos] & 0x7f) == 127) else 1
+    return flag, pos
 
 
 def range_depends_on_prior_state(bits, bpos, offsets, nentered, nblk, mode512=True, first_is_iframe=True):
-    """True when the pixels of a range may depend on img_data / iframe_data from before its first frame.
-    bits [n, stride] uint8, bpos [n], offsets [n, nblk] (byte position at which each block is entered), nentered [n].
+    """True when the pixels of a range may depend on img_data / iframe_data from before its first frame.  (Host-side form for
+    callers that hold the parser's outputs; a GPU decode reports the same fact itself, AgmvHip.decode_depends_on_prior().)
+    bits [n, stride] uint8, bpos [n], offsets [n, nblk] (byte position at which each block is ENTERED, i.e. before the
+    flag resync), nentered [n].
       (a) a frame that raises `escape` leaves blocks >= nentered at the previous frame's values;
-      (b) a COPY block in the range's first frame reads the snapshot taken before the range;
-      (c) a NORMAL block that runs past bpos stops writing pixels (per-pixel over-run check, :310-314 / :386-392);
-          followed by another block that is case (a), as the LAST block of a frame it has to be looked at itself.
+      (b) a COPY block in the range's first frame reads the snapshot taken before the range.  A block is decoded under the
+          first flag-valued byte at or after its entry position, so that byte is what is classified;
+      (c) a block that runs past bpos is not (FILL, :268-271) or not completely (NORMAL, per-pixel check :310-314 /
+          :386-392) stored.  Inside a frame that ends the frame (case a); as the LAST block it has to be looked at itself.
     Everything else a frame writes is a function of its own bitstream and of frames inside the range."""
     n = int(nentered.numel())
     if n == 0:
@@ -102,23 +129,18 @@ def range_depends_on_prior_state(bits, bpos, offsets, nentered, nblk, mode512=Tr
         return True
     if not first_is_iframe:
         return True                                           # the range continues a GOP of the caller's
-    flags = bits[0].gather(0, offsets[0].to(torch.int64))
-    if bool((flags == COPY_FLAG).any()):
-        return True
-    # (c): length of every frame's last block (<= 33 bytes), walked on the host for all frames at once
-    start = offsets[:, nblk - 1].to(torch.int64)
-    idx = (start[:, None] + torch.arange(34, device=bits.device)[None, :]).clamp_(max=bits.shape[1] - 1)
-    win = bits.gather(1, idx).cpu().numpy()
-    end = start.cpu().numpy().copy()
-    for f in range(n):
-        w = win[f]
-        if w[0] != NORMAL_FLAG:
-            continue                                          # FILL / COPY write all 16 pixels whatever they read
-        pos = 1
-        for _ in range(16):
-            pos += 2 if (mode512 and (w[pos] & 0x7f) == 127) else 1
-        end[f] += pos
-    return bool((end > bpos.cpu().numpy().astype(end.dtype)).any())
+    bp = bpos.cpu().numpy().astype("int64")
+    off = offsets.cpu().numpy().astype("int64")
+    first = bits[0].cpu().numpy()
+    for k in range(nblk):                                     # (b), and (c) for the resync of every block of the first frame
+        flag, _ = _block_end(first, int(off[0, k]), int(bp[0]), mode512)
+        if flag is None or flag == COPY_FLAG:
+            return True
+    for f in range(n):                                        # (c): the last block of every frame
+        flag, end = _block_end(bits[f].cpu().numpy(), int(off[f, nblk - 1]), int(bp[f]), mode512)
+        if flag is None or (flag != COPY_FLAG and end > int(bp[f])):
+            return True
+    return False
 
 
 def decode_sharded(dist, decode_range, n_frames, first_frame_count=0, prev=None, prev_iframe=None):

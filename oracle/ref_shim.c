@@ -21,6 +21,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <stdint.h>
+#include <stddef.h>
 
 #include <agmv.h>
 
@@ -257,3 +258,60 @@ void refshim_interp(uint32_t* out, const uint32_t* f1, const uint32_t* f2, uint3
 	for (i = 0; i < n; i++) out[i] = (uint32_t)o[i];
 	free(a); free(b); free(o);
 }
+
+/* ---- E5-E8 on a GIVEN entry plane (the exported helpers, src/agmv_encode.c:240-527) ---------- */
+/* entries are pal_num << 8 | index; the plane is widened to AGMV_ENTRY and handed to the reference's
+   own AGMV_Assemble{I,P}FrameBitstream; returns the bytes appended at bitstream->pos = 0. */
+static AGMV_ENTRY* widen_entries(const uint16_t* e, size_t n)
+{
+	AGMV_ENTRY* w = (AGMV_ENTRY*)calloc(n, sizeof(AGMV_ENTRY));
+	size_t i;
+	for (i = 0; i < n; i++) { w[i].pal_num = (u8)(e[i] >> 8); w[i].index = (u8)e[i]; }
+	return w;
+}
+
+void refshim_set_iframe_entries(AGMV* a, const uint16_t* e)
+{
+	size_t n = (size_t)AGMV_GetWidth(a) * AGMV_GetHeight(a), i;
+	for (i = 0; i < n; i++) { a->iframe_entries[i].pal_num = (u8)(e[i] >> 8); a->iframe_entries[i].index = (u8)e[i]; }
+}
+
+size_t refshim_assemble(AGMV* a, const uint16_t* entries, int iframe, uint8_t* out)
+{
+	size_t n = (size_t)AGMV_GetWidth(a) * AGMV_GetHeight(a);
+	AGMV_ENTRY* w = widen_entries(entries, n);
+	a->bitstream->pos = 0;
+	if (iframe) AGMV_AssembleIFrameBitstream(a, w); else AGMV_AssemblePFrameBitstream(a, w);
+	memcpy(out, a->bitstream->data, a->bitstream->pos);
+	free(w);
+	return a->bitstream->pos;
+}
+
+unsigned refshim_compare_i(AGMV* a, uint32_t x, uint32_t y, uint32_t color, const uint16_t* entries)
+{
+	size_t n = (size_t)AGMV_GetWidth(a) * AGMV_GetHeight(a);
+	AGMV_ENTRY* w = widen_entries(entries, n);
+	unsigned c = AGMV_CompareIFrameBlock(a, x, y, color, w);
+	free(w);
+	return c;
+}
+
+unsigned refshim_compare_p(AGMV* a, uint32_t x, uint32_t y, const uint16_t* entries)
+{
+	size_t n = (size_t)AGMV_GetWidth(a) * AGMV_GetHeight(a);
+	AGMV_ENTRY* w = widen_entries(entries, n);
+	unsigned c = AGMV_ComparePFrameBlock(a, x, y, w);
+	free(w);
+	return c;
+}
+
+/* ---- N4: field access for the playback tests (same struct layout in both libraries) ------------ */
+uint32_t refshim_offset_table(AGMV* a, uint32_t i) { return (uint32_t)a->offset_table[i]; }
+void refshim_frame_pixels(AGMV* a, uint32_t* out)
+{
+	size_t n = (size_t)a->frame->width * a->frame->height, i;
+	for (i = 0; i < n; i++) out[i] = (uint32_t)a->frame->img_data[i];
+}
+/* a decoder object the way a player sets one up (tools/agmvp: CreateAGMV, then AGMV_DecodeHeader on the open file) */
+size_t refshim_offsetof_frame_count(void) { return offsetof(AGMV, frame_count); }
+size_t refshim_offsetof_offset_table(void) { return offsetof(AGMV, offset_table); }

@@ -542,7 +542,53 @@ def test_full_size_properties(torch, hip):
         assert len(got) == len(exp) and (got == exp).all()
 
 
-@pytest.mark.parametrize("kind", ["clean", "escape", "copy", "overrun"])
+@pytest.mark.parametrize("shape", [(1920, 1080), (1280, 720)])
+def test_decode_full_size_vs_oracle(torch, hip, shape):
+    """configs 3 and 5 at their real frame sizes: parse + reconstruct of two GOPs against the oracle decoder, pixel for pixel"""
+    W, H = shape
+    frames = np.stack([S.synth_frame(W, H, t) for t in range(8)])
+    p0, p1 = S.content_palettes(frames[:4])
+    hip.set_palette(p0, p1, True)
+    bits = gpu_encode(torch, hip, frames)
+    got, _, nent = gpu_decode(torch, hip, bits, None, W, H)
+    assert (nent == W * H // 16).all()
+    dec = O.OracleDecoder(W, H, True, p0, p1)
+    for t in range(8):
+        exp = dec.decode(bits[t])
+        assert (got[t] == exp).all(), "frame %d: %d pixels differ" % (t, int((got[t] != exp).sum()))
+
+
+def test_c3_full_batch_vs_oracle(torch, hip):
+    """config 3 at its real batch size -- 1024 resident 1080p frames in ONE encode / parse / decode (254 tiles x 1024 status
+    words, 260 096 tickets): the first, a middle and the last GOP against the oracle, byte for byte and pixel for pixel"""
+    W, H, T = 1920, 1080, 1024
+    free, _ = torch.cuda.mem_get_info()
+    if free < 30 * (1 << 30):
+        pytest.skip("needs ~25 GB of device memory")
+    frames = hip.synth_dev(W, H, 0, T)
+    p0, p1 = S.content_palettes([S.synth_frame(W, H, t) for t in range(2)])
+    hip.set_palette(p0, p1, True)
+    out, sizes = hip.encode_dev(frames, T, W, H)
+    hip.check()
+    offs, nent = hip.parse_dev(out, sizes, T, W, H)
+    dec = hip.decode_dev(out, sizes, offs, nent, T, W, H)
+    torch.cuda.synchronize()
+    assert hip.decode_depends_on_prior(W, H) is False
+    sz = sizes.cpu().numpy()
+    assert (nent.cpu().numpy() == W * H // 16).all() and (sz > 0).all() and (sz < hip.max_usize(W, H)).all()
+    for g0 in (0, 508, 1020):
+        enc = O.OracleEncoder(W, H, True, p0, p1, first_frame_count=g0)
+        odec = O.OracleDecoder(W, H, True, p0, p1)
+        odec.s.frame_count = g0
+        for t in range(g0, g0 + 4):
+            exp = enc.encode(S.synth_frame(W, H, t))
+            got = out[t, :sz[t]].cpu().numpy()
+            assert len(got) == len(exp) and (got == exp).all(), "frame %d first diff %s" % (t, first_diff(got, exp))
+            pix = odec.decode(exp)
+            assert (to_u32(dec[t]).reshape(-1) == pix).all(), "decoded frame %d" % t
+
+
+@pytest.mark.parametrize("kind", ["clean", "escape", "copy", "overrun", "fill_cut", "garbage_copy"])
 def test_gop_range_decode_and_dependency_predicate(torch, hip, kind):
     """what libagmv_amd.shard.decode_sharded relies on, with the real parser and k_decode: a GOP range decoded on its
     own (fresh decoder state) equals the serial decode unless shard.range_depends_on_prior_state says it depends on
@@ -561,6 +607,10 @@ def test_gop_range_decode_and_dependency_predicate(torch, hip, kind):
         bits[8] = np.full(nblk, 0x5E, np.uint8)
     elif kind == "overrun":                                    # the range's first frame: FILL blocks, then a last NORMAL block the stream ends inside
         bits[8] = np.concatenate([np.tile(np.array([0x4E, 7], np.uint8), nblk - 1), np.array([0x2F, 1, 2, 3, 4, 5], np.uint8)])
+    elif kind == "fill_cut":                                   # every block entered, but the last FILL's index byte lies behind bpos:
+        bits[8] = np.tile(np.array([0x4E, 7], np.uint8), nblk)[:-1]   # the reference does not store it (src/agmv_decode.c:268-271)
+    elif kind == "garbage_copy":                               # block 0 is entered on a non-flag byte and slides to a COPY flag (:236-243)
+        bits[8] = np.concatenate([np.array([0x00, 0x5E], np.uint8), np.tile(np.array([0x4E, 9], np.uint8), nblk - 1)])
     dec = O.OracleDecoder(W, H, True, p0, p1)
     exp, pads = [], []
     for b in bits:
@@ -578,6 +628,8 @@ def test_gop_range_decode_and_dependency_predicate(torch, hip, kind):
                                              torch.from_numpy(offs.astype(np.int64)), torch.from_numpy(nent.astype(np.int32)), nblk, True)
     same = all((alone[i] == exp[cut + i]).all() for i in range(T - cut))
     assert dep == (kind != "clean")
+    # the decoder's own account of the same fact (what a sharded GPU decode uses): the last decode on `hip` was `alone`
+    assert hip.decode_depends_on_prior(W, H) == dep
     if not dep:
         assert same
     else:
