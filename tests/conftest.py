@@ -23,3 +23,17 @@ def golden():
 @pytest.fixture(scope="session")
 def golden_dir():
     return os.path.join(HERE, "golden")
+
+
+@pytest.fixture(scope="session")
+def golden_fox():
+    """real-content fixtures made by tests/golden/make_golden_foxlogo.py from the reference's own foxlogo assets"""
+    import json
+    return json.load(open(os.path.join(HERE, "golden", "golden_foxlogo.json")))
+
+
+@pytest.fixture(scope="session")
+def foxlogo():
+    import numpy as np
+    z = np.load(os.path.join(HERE, "golden", "foxlogo.npz"))
+    return {"frames": z["frames"], "p0": z["p0"], "p1": z["p1"]}

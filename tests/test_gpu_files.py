@@ -69,6 +69,44 @@ def test_file_roundtrip_matches_reference(golden, tmp_path, name):
         assert os.path.exists(tmp_path / "GBA_GEN_AGMV.h")
 
 
+def test_foxlogo_through_the_readme_flow(golden_fox, foxlogo, tmp_path):
+    """real content through the drop-in API: the first 24 frames of the reference's foxlogo sample -> CreateAGMV +
+    AGMV_EncodeAGMV (OPT_III / LOW / LZSS, the README flow) -> AGMV_DecodeAGMV; file and decoded BMPs as the compiled
+    reference makes them (tests/golden/make_golden_foxlogo.py)"""
+    g = golden_fox["encodeagmv_24"]
+    H.lib()
+    (tmp_path / "fr").mkdir()
+    for k, f in enumerate(foxlogo["frames"]):
+        H.write_bmp(str(tmp_path / "fr" / ("f%d.bmp" % (k + 1))), f)
+    r = subprocess.run([sys.executable, "-c", DRIVER % H.SO, "agmv", "24", "320", "240", str(g["opt"]), str(g["quality"]),
+                        str(g["compression"]), "8"], cwd=str(tmp_path), stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=600)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    data = open(tmp_path / "out.agmv", "rb").read()
+    assert (int.from_bytes(data[4:8], "little"), int.from_bytes(data[18:22], "little"), len(data)) == (g["frames"], g["fps_field"], g["file_len"])
+    assert hashlib.sha256(data).hexdigest() == g["file_sha"], "the .agmv file differs from the reference's"
+    h = hashlib.sha256()
+    for k in range(1, g["frames"] + 1):
+        h.update(open(tmp_path / ("quick_export_%d.bmp" % k), "rb").read())
+    assert h.hexdigest() == g["decoded_bmps_sha"], "decoded BMPs differ from the reference's"
+
+
+@pytest.mark.parametrize("which", ["FOXLOGO"])
+def test_decode_sample_with_audio_chunks_via_c_api(golden_fox, golden_dir, tmp_path, which):
+    """AGMV_DecodeAGMV on a stream with AGAC chunks between the frames (audio itself is out of scope: the chunks are skipped)"""
+    import numpy as np
+    g = golden_fox[which]
+    code = "import ctypes as C,sys; L=C.CDLL(%r); L.AGMV_DecodeAGMV.argtypes=[C.c_char_p,C.c_ubyte,C.c_int]; sys.exit(L.AGMV_DecodeAGMV(%r,1,1))" % (
+        H.SO, os.path.join(golden_dir, which + ".agmv").encode())
+    H.lib()
+    r = subprocess.run([sys.executable, "-c", code], cwd=str(tmp_path), stderr=subprocess.PIPE, timeout=300)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    for k in (1, 2, 40, 64, g["n"]):
+        raw = open(tmp_path / ("quick_export_%d.bmp" % k), "rb").read()
+        px = np.frombuffer(raw[54:], np.uint8).reshape(-1, 3).astype(np.uint32)
+        pix = px[:, 2] << 16 | px[:, 1] << 8 | px[:, 0]
+        assert hashlib.sha256(pix.astype(np.uint32).tobytes()).hexdigest() == g["pix_sha"][k - 1], k
+
+
 def test_decode_reference_sample_file_via_c_api(golden, golden_dir, tmp_path):
     """config 1 through the drop-in API: AGMV_DecodeAGMV(agmv_splash.agmv) -> 119 BMPs whose pixels are the golden ones"""
     import numpy as np

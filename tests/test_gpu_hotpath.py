@@ -224,12 +224,14 @@ def test_roundtrip_vs_oracle(torch, hip, mode512):
         assert (got[t] == exp[t]).all(), "pixels frame %d" % t
 
 
-def test_decode_reference_sample_file(torch, hip, golden, golden_dir):
-    """config 1's file: the host oracle runs the LZ stage (host-side by design) and hands the
-    decompressed buffers -- INCLUDING the stale bytes beyond bpos -- to the GPU; 37 of the 119
-    frames raise `escape`, so stale tails, the fix-up pass and the last-block quirk are all hit."""
-    g = golden["agmv_splash"]
-    data = open(os.path.join(golden_dir, "agmv_splash.agmv"), "rb").read()
+@pytest.mark.parametrize("which", ["agmv_splash", "FOXLOGO"])
+def test_decode_reference_sample_file(torch, hip, golden, golden_fox, golden_dir, which):
+    """the reference's own sample streams (config 1's agmv_splash.agmv; examples/simple_decoding/FOXLOGO.agmv with audio
+    chunks): the host oracle runs the LZ stage (host-side by design) and hands the decompressed buffers -- INCLUDING the
+    stale bytes beyond bpos -- to the GPU; 37 of 119 / 64 of 105 frames raise `escape`, so stale tails, the fix-up pass and
+    the last-block quirk are all hit."""
+    g = golden["agmv_splash"] if which == "agmv_splash" else golden_fox["FOXLOGO"]
+    data = open(os.path.join(golden_dir, which + ".agmv"), "rb").read()
     err, info, fr = O.oracle_decode_file(data, want_tables=True)
     assert err == 0
     p0 = np.zeros(256, np.uint32)
@@ -254,6 +256,29 @@ def test_decode_reference_sample_file(torch, hip, golden, golden_dir):
     last_i = (k - 1) // 4 * 4
     b, _, _ = gpu_decode(torch, hip, bits[k:], pads[k:], info.w, info.h, first_fc=k, prev=a[k - 1], prev_iframe=a[last_i])
     assert [sha(x) for x in list(a) + list(b)] == g["pix_sha"]
+
+
+def test_encode_foxlogo_frames_golden(torch, hip, golden_fox, foxlogo):
+    """real content: foxlogo frames 10..13 as I,P,P,P with the reference-built foxlogo palette --
+    duplicate zero slots in the palettes, FILL / COPY counts on the borderline, both colour modes; then all 24 stored frames
+    in one batch against the oracle"""
+    fr, p0, p1 = foxlogo["frames"], foxlogo["p0"], foxlogo["p1"]
+    for mode512, name in ((True, "opt3"), (False, "opt2")):
+        g = golden_fox["ippp_" + name]
+        hip.set_palette(p0, p1, mode512)
+        ient = torch.zeros(320 * 240, dtype=torch.int16, device="cuda")
+        outs = gpu_encode(torch, hip, fr[9:13], ientries=ient)
+        assert [len(o) for o in outs] == g["usize"]
+        assert [sha(o) for o in outs] == g["bytes_sha"]
+        ent = to_u16(hip.quantise_dev(dev_u32(torch, fr[9])))
+        if not mode512:
+            ent = ent & 0xFF
+        assert sha(ent) == g["entries_sha"][0]
+        whole = gpu_encode(torch, hip, fr)
+        enc = O.OracleEncoder(320, 240, mode512, p0, p1)
+        for t in range(len(fr)):
+            exp = enc.encode(fr[t])
+            assert len(whole[t]) == len(exp) and (whole[t] == exp).all(), (name, t)
 
 
 def test_decode_truncated_and_garbage_streams(torch, hip):

@@ -71,6 +71,33 @@ def test_decode_splash_golden(golden, golden_dir):
     assert sum(1 for f in frames if f["bpos"] != f["usize"]) == 37
 
 
+def test_foxlogo_frames_golden(golden_fox, foxlogo):
+    """real content: frames 10..13 of the reference's foxlogo sample coded I,P,P,P with the palette of the reference's own
+    foxlogo file, both colour modes -- the known answers of SURVEY.md Appendix C (b166e3c8..., 8b025027..., ccbfe015..., ...)"""
+    fr, p0, p1 = foxlogo["frames"], foxlogo["p0"], foxlogo["p1"]
+    for mode512, name in ((True, "opt3"), (False, "opt2")):
+        g = golden_fox["ippp_" + name]
+        enc = O.OracleEncoder(320, 240, mode512, p0, p1)
+        for k in range(4):
+            b, e = enc.encode(fr[9 + k], True)
+            assert len(b) == g["usize"][k] and sha(b) == g["bytes_sha"][k] and sha(e) == g["entries_sha"][k], (name, k)
+    assert golden_fox["ippp_opt3"]["bytes_sha"][0].startswith("b166e3c865c5fff5")
+    assert golden_fox["ippp_opt2"]["bytes_sha"][3].startswith("a14138cb309803387")
+
+
+def test_decode_foxlogo_sample_golden(golden_fox, golden_dir):
+    """the reference's second sample stream (examples/simple_decoding/FOXLOGO.agmv: audio chunks between the frames, 64 of
+    105 frames decompress to bpos != usize)"""
+    g = golden_fox["FOXLOGO"]
+    data = open(os.path.join(golden_dir, "FOXLOGO.agmv"), "rb").read()
+    assert hashlib.sha256(data).hexdigest() == g["file_sha"]
+    err, info, frames = O.oracle_decode_file(data)
+    assert err == 0 and (info.w, info.h, info.num_frames, info.version) == (g["w"], g["h"], g["n"], g["version"])
+    assert [f["usize"] for f in frames] == g["usize"] and [f["bpos"] for f in frames] == g["bpos"]
+    assert [sha(f["pix"]) for f in frames] == g["pix_sha"]
+    assert sum(1 for f in frames if f["bpos"] != f["usize"]) == g["escape_frames"] == 64
+
+
 def test_old_header_rejected(golden_dir):
     data = open(os.path.join(golden_dir, "agmv_spash_header.bin"), "rb").read()
     err, _, _ = O.oracle_decode_file(data)
