@@ -1620,93 +1620,69 @@ __global__ __launch_bounds__(DEC_T, DEC_WPE) void k_decode(DecArgs A)
 	}
 }
 
-// K4: sequential repair.  A single wave gathers up to 64 dirty block positions per pass and
-// replays ALL frames for them in order, starting from the true pre-batch state, overwriting the
-// output.  The left neighbour of the last block rides along so the FILL quirk sees its value.
+// K4: repair of the blocks k_decode flagged.  The blocks are independent of each other (a block's pixels in frame f derive
+// from the SAME block in earlier frames) with one exception, the last block of the frame, whose FILL takes a pixel of its
+// left neighbour (src/agmv_decode.c:264-266).  So the grid is one wave per 64 consecutive block positions; a wave whose
+// 64 bitmap bits are clear exits at once, the others replay ALL frames in order for their flagged positions from the true
+// pre-batch state and overwrite the output.  The wave that holds block nblk-1 also replays block nblk-2 (flagged or not:
+// a replay from the true state writes the true pixels), in the lane below when both sit in one wave, else in lane 1.
 template <bool M512>
 __global__ __launch_bounds__(64) void k_fixup(DecArgs A)
 {
 	__shared__ uint32_t s_pal[512];
-	__shared__ uint32_t s_list[64];
-	__shared__ uint32_t s_w[64];
-	__shared__ uint32_t s_cnt, s_next, s_more;
 	const int lane = threadIdx.x;
 	const uint32_t npx = A.w * A.h;
 	const uint32_t nwords = (A.nblk + 31) >> 5;
 	if (A.dirty[nwords] == 0) return;                          // nothing depends on an earlier GOP: done
+	const uint32_t base = blockIdx.x * 64u;
+	const uint32_t w0 = A.dirty[base >> 5], w1 = (base >> 5) + 1 < nwords ? A.dirty[(base >> 5) + 1] : 0u;
+	if ((w0 | w1) == 0) return;
+	uint32_t blk = base + (uint32_t)lane;
+	bool active = blk < A.nblk && (((lane < 32 ? w0 : w1) >> (lane & 31)) & 1u);
+	// the last block's left neighbour rides along
+	const uint32_t last = A.nblk - 1;
+	const bool have_last = last >= base && last < base + 64 && ((((last - base) < 32 ? w0 : w1) >> ((last - base) & 31)) & 1u);
+	int nb_lane = -1;                                          // lane that holds block nblk-2 when this wave repairs nblk-1
+	if (have_last && A.nblk >= 2) {
+		if (last > base) { nb_lane = (int)(last - base) - 1; if (lane == nb_lane) active = true; }
+		else { nb_lane = 1; if (lane == 1) { blk = last - 1; active = true; } }       // nblk-1 is lane 0: lane 1 (a block beyond the frame) takes nblk-2
+	}
 	for (int i = lane; i < 512; i += 64) s_pal[i] = A.pal[i];
-	if (lane == 0) s_next = 0;
 	__syncthreads();
-	for (;;) {
-		// ---- collect the next (up to 64) dirty positions in increasing order: 64 bitmap words per
-		// step are fetched by the whole wave, lane 0 walks their bits out of LDS
-		if (lane == 0) { s_cnt = 0; s_more = 1; }
-		__syncthreads();
-		while (s_more) {
-			const uint32_t pos0 = s_next, wbase = pos0 >> 5;
-			s_w[lane] = (wbase + lane < nwords) ? A.dirty[wbase + lane] : 0u;
-			__syncthreads();
-			if (lane == 0) {
-				uint32_t cnt = s_cnt, pos = pos0;
-				const uint32_t lim = min(A.nblk, (wbase + 64u) << 5);
-				bool full = false;
-				while (pos < lim) {
-					uint32_t wd = s_w[(pos >> 5) - wbase] >> (pos & 31u);
-					if (wd == 0) { pos = (pos | 31u) + 1; continue; }
-					pos += (uint32_t)__ffs((int)wd) - 1;
-					if (pos >= lim) break;
-					const bool pair = pos == A.nblk - 1 && A.nblk >= 2 && (cnt == 0 || s_list[cnt - 1] != A.nblk - 2);
-					if (cnt + (pair ? 2u : 1u) > 64u) { full = true; break; }   // keep the pair in one pass
-					if (pair) s_list[cnt++] = A.nblk - 2;
-					s_list[cnt++] = pos;
-					pos++;
-				}
-				if (pos > A.nblk) pos = A.nblk;
-				s_cnt = cnt;
-				s_next = pos;
-				s_more = (!full && cnt < 64 && pos < A.nblk) ? 1u : 0u;
-			}
-			__syncthreads();
-		}
-		const uint32_t cnt = s_cnt;
-		if (cnt == 0) break;
-		const bool active = (uint32_t)lane < cnt;
-		const uint32_t blk = active ? s_list[lane] : 0;
-		const uint32_t by = blk / A.bw, bx = blk - by * A.bw;
-		const uint32_t poff = by * 4 * A.w + bx * 4;
-		const bool is_last = active && blk == A.nblk - 1;
-		uint32_t cur[16], icol[16];
-		if (A.prev) load_block(A.prev, poff, A.w, cur);
-		else {
+	if (!active) blk = 0;
+	const uint32_t by = blk / A.bw, bx = blk - by * A.bw;
+	const uint32_t poff = by * 4 * A.w + bx * 4;
+	const bool is_last = active && blk == last;
+	uint32_t cur[16], icol[16];
+	if (A.prev) load_block(A.prev, poff, A.w, cur);
+	else {
 #pragma unroll
-			for (int k = 0; k < 16; k++) cur[k] = 0;
-		}
-		if (A.prev_iframe) load_block(A.prev_iframe, poff, A.w, icol);
-		else {
+		for (int k = 0; k < 16; k++) cur[k] = 0;
+	}
+	if (A.prev_iframe) load_block(A.prev_iframe, poff, A.w, icol);
+	else {
 #pragma unroll
-			for (int k = 0; k < 16; k++) icol[k] = 0;
+		for (int k = 0; k < 16; k++) icol[k] = 0;
+	}
+	for (uint32_t f = 0; f < A.n_frames; f++) {
+		bool stale = false, fill_written = false;
+		const uint32_t own3 = cur[3];
+		if (active && blk < A.nentered[f]) {
+			ByteSrc src{A.bits + (size_t)f * A.stride, (uint32_t)A.stride};
+			decode_block<M512>(src, A.offsets[(size_t)f * A.nblk + blk], A.bpos[f], s_pal, cur, icol,
+			                   false, stale, fill_written);
 		}
-		for (uint32_t f = 0; f < A.n_frames; f++) {
-			bool stale = false, fill_written = false;
-			const uint32_t own3 = cur[3];
-			if (active && blk < A.nentered[f]) {
-				ByteSrc src{A.bits + (size_t)f * A.stride, (uint32_t)A.stride};
-				decode_block<M512>(src, A.offsets[(size_t)f * A.nblk + blk], A.bpos[f], s_pal, cur, icol,
-				                   false, stale, fill_written);
-			}
-			uint32_t left = __shfl_up(cur[7], 1, 64);          // neighbour sits in lane-1 by construction
-			if (is_last && fill_written && (lane > 0 || A.bw == 1)) {
-				const uint32_t c = A.bw == 1 ? own3 : left;        // one block per row: see k_decode
+		const uint32_t left = (uint32_t)__builtin_amdgcn_readlane((int)cur[7], nb_lane < 0 ? 0 : nb_lane);   // img_data[(x-1)+(y+1)*w] of the left neighbour
+		if (is_last && fill_written) {
+			const uint32_t c = A.bw == 1 ? own3 : left;            // one block per row: see k_decode
 #pragma unroll
-				for (int k = 0; k < 16; k++) cur[k] = c;
-			}
-			if (((A.first_fc + f) & 3u) == 0) {
-#pragma unroll
-				for (int k = 0; k < 16; k++) icol[k] = cur[k];
-			}
-			if (active) store_block(A.out + (size_t)f * npx, poff, A.w, cur);
+			for (int k = 0; k < 16; k++) cur[k] = c;
 		}
-		__syncthreads();
+		if (((A.first_fc + f) & 3u) == 0) {
+#pragma unroll
+			for (int k = 0; k < 16; k++) icol[k] = cur[k];
+		}
+		if (active) store_block(A.out + (size_t)f * npx, poff, A.w, cur);
 	}
 }
 
@@ -2248,11 +2224,11 @@ extern "C" int agmv_hip_decode_frames_dev(agmv_hip_ctx* c, const uint8_t* d_bits
 	if (c->mode512) {
 		hipLaunchKernelGGL(k_decode<true>, dim3(A.n_groups * A.tpf), dim3(DEC_T), 0, s, A);
 		CK(hipGetLastError());
-		hipLaunchKernelGGL(k_fixup<true>, dim3(1), dim3(64), 0, s, A);
+		hipLaunchKernelGGL(k_fixup<true>, dim3((A.nblk + 63) / 64), dim3(64), 0, s, A);
 	} else {
 		hipLaunchKernelGGL(k_decode<false>, dim3(A.n_groups * A.tpf), dim3(DEC_T), 0, s, A);
 		CK(hipGetLastError());
-		hipLaunchKernelGGL(k_fixup<false>, dim3(1), dim3(64), 0, s, A);
+		hipLaunchKernelGGL(k_fixup<false>, dim3((A.nblk + 63) / 64), dim3(64), 0, s, A);
 	}
 	CK(hipGetLastError());
 	ev_mark(c, 5, s);

@@ -613,6 +613,45 @@ def test_c3_full_batch_vs_oracle(torch, hip):
             assert (to_u32(dec[t]).reshape(-1) == pix).all(), "decoded frame %d" % t
 
 
+def test_decode_heavily_truncated_1080p(torch, hip):
+    """thousands of stale blocks per frame: every frame of a 64-frame 1080p clip is cut at about half its length, so the lower
+    half of each picture keeps earlier pixels across GOPs (reference src/agmv_decode.c:229-232) -- the repair pass (k_fixup,
+    one wave per 64 block positions) against the oracle decoder, and a clip whose only damaged frame is the very last block"""
+    W, H, T = 1920, 1080, 64
+    frames = hip.synth_dev(W, H, 0, T)
+    p0, p1 = S.content_palettes([S.synth_frame(W, H, t) for t in range(2)])
+    hip.set_palette(p0, p1, True)
+    out, sizes = hip.encode_dev(frames, T, W, H)
+    hip.check()
+    sz = sizes.cpu().numpy()
+    full = [out[t, :sz[t]].cpu().numpy() for t in range(T)]
+    rng = np.random.default_rng(4)
+    cut = [b[:int(len(b) * (0.35 + 0.3 * rng.random()))] if t else b for t, b in enumerate(full)]   # frame 0 whole: a known picture underneath
+    dec = O.OracleDecoder(W, H, True, p0, p1)
+    exp, pads = [], []
+    for b in cut:
+        pix, padded, _, _ = dec.decode(b, want_tables=True)
+        exp.append(pix)
+        pads.append(padded[len(b):len(b) + 16])
+    hip.enable_timing(True)
+    got, _, nent = gpu_decode(torch, hip, cut, pads, W, H)
+    ms = hip.last_kernel_ms(2)
+    hip.enable_timing(False)
+    assert (nent[1:] < W * H // 16).all() and hip.decode_depends_on_prior(W, H) is False    # stale, but nothing from before the batch
+    for t in range(T):
+        assert (got[t] == exp[t]).all(), "frame %d: %d pixels differ" % (t, int((got[t] != exp[t]).sum()))
+    print("k_decode + k_fixup, 64 x 1080p, every frame truncated: %.3f ms" % ms)
+    # only the last block is damaged (its FILL is cut off), in a P-frame: the repair involves the left neighbour only
+    one = list(full[:8])
+    nblk = W * H // 16
+    one[5] = np.concatenate([np.tile(np.array([0x4E, 3], np.uint8), nblk - 1), np.array([0x4E], np.uint8)])
+    dec = O.OracleDecoder(W, H, True, p0, p1)
+    exp1 = [dec.decode(b) for b in one]
+    got1, _, _ = gpu_decode(torch, hip, one, None, W, H)
+    for t in range(8):
+        assert (got1[t] == exp1[t]).all(), "frame %d" % t
+
+
 @pytest.mark.parametrize("kind", ["clean", "escape", "copy", "overrun", "fill_cut", "garbage_copy"])
 def test_gop_range_decode_and_dependency_predicate(torch, hip, kind):
     """what libagmv_amd.shard.decode_sharded relies on, with the real parser and k_decode: a GOP range decoded on its
