@@ -273,6 +273,9 @@ void AGMV_ExportAGMVToHeader(const char* filename);
    threads for the LZ stage (default: online cores, env AGMV_LZ_THREADS) */
 void AGMV_SetBatchFrames(unsigned frames);
 void AGMV_SetLZThreads(unsigned threads);
+/* GPUs the sequence encoders (AGMV_EncodeAGMV / EncodeFullAGMV / EncodeVideo) spread their GOP-aligned batches over, from this
+   one host process (default 1; env AGMV_DEVICES); the output is the same file whatever the number */
+void AGMV_SetDevices(unsigned devices);
 /* canonical synthetic clip agmv_synth_v1: frame t as 4-byte 0x00RRGGBB pixels */
 void AGMV_SynthFrame(unsigned* pix, unsigned w, unsigned h, unsigned t, unsigned long long seed);
 /* palette build of the encoders (reference src/agmv_encode.c:2364-2656) from a 2^19-bin histogram

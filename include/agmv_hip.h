@@ -166,7 +166,22 @@ float agmv_hip_last_kernel_ms(agmv_hip_ctx* ctx, int which);
 /* check for an asynchronous device-side failure (look-back timeout) after synchronising */
 int agmv_hip_check(agmv_hip_ctx* ctx, void* stream);
 
-/* raw device memory for C hosts that do not link the HIP runtime themselves */
+/* streams, pinned host staging and asynchronous copies for C hosts that do not link the HIP runtime themselves (the
+   pipelined sequence drivers: H2D || kernels || D2H || host LZ).  The *_on / *_async forms act on the context's device;
+   kind: 0 = host to device, 1 = device to host, 2 = device to device.  Host memory of asynchronous copies must come from
+   agmv_hip_host_alloc. */
+void* agmv_hip_stream_create(agmv_hip_ctx* ctx);
+void  agmv_hip_stream_destroy(agmv_hip_ctx* ctx, void* stream);
+int   agmv_hip_stream_sync(agmv_hip_ctx* ctx, void* stream);
+void* agmv_hip_host_alloc(size_t bytes);
+void  agmv_hip_host_free(void* h);
+void* agmv_hip_malloc_on(agmv_hip_ctx* ctx, size_t bytes);
+void  agmv_hip_free_on(agmv_hip_ctx* ctx, void* d);
+int   agmv_hip_memcpy_async(agmv_hip_ctx* ctx, void* dst, const void* src, size_t n, int kind, void* stream);
+int   agmv_hip_memset_async(agmv_hip_ctx* ctx, void* d, int v, size_t n, void* stream);
+int   agmv_hip_ctx_device(agmv_hip_ctx* ctx);
+
+/* raw device memory for C hosts that do not link the HIP runtime themselves (current device) */
 void* agmv_hip_malloc(size_t bytes);
 void  agmv_hip_free(void* d);
 int   agmv_hip_memcpy_h2d(void* d, const void* h, size_t bytes);

@@ -22,12 +22,13 @@
 
 #include "agmv_hip.h"
 #include "agmv_internal.h"
+#include "agmv_pipeline.h"
 
 /* ------------------------------------------------------------------------------------------ */
 static agmv_hip_ctx* g_ctx = NULL;
 static uint32_t g_pal[512];
 static int g_pal_mode = -1;
-static unsigned g_batch_frames = 0, g_lz_threads = 0;
+static unsigned g_batch_frames = 0, g_lz_threads = 0, g_devices = 0;
 static unsigned long g_export_count = 0;            /* AGIDL's expcount, extern/agidl/src/agidl_img_export.c:18 */
 
 void agmv_die(const char* what)
@@ -51,22 +52,50 @@ static int bad_geometry(uint32_t w, uint32_t h)
 
 void AGMV_SetBatchFrames(unsigned n) { g_batch_frames = n; }
 void AGMV_SetLZThreads(unsigned n) { g_lz_threads = n; }
+void AGMV_SetDevices(unsigned n) { g_devices = n; }
 
-static unsigned batch_frames(void)
+/* frames per GPU batch: what the caller asked for, else about 128 MB of source pixels (64 frames at most), whole GOPs */
+static unsigned batch_frames(size_t npx)
 {
 	unsigned n = g_batch_frames;
 	const char* e = getenv("AGMV_BATCH_FRAMES");
 	if (!n && e) n = (unsigned)atoi(e);
-	if (!n) n = 64;
-	return (n + 3u) & ~3u;                           /* whole GOPs */
+	if (!n) {
+		size_t f = ((size_t)128 << 20) / (npx ? npx * 4 : 4);
+		n = f < 8 ? 8 : (f > 64 ? 64 : (unsigned)f);
+	}
+	return (n + 3u) & ~3u;
 }
 
+/* GPUs the sequence encoders spread their batches over (AGMV_SetDevices / env AGMV_DEVICES; default 1) */
+static unsigned devices(void)
+{
+	unsigned n = g_devices;
+	const char* e = getenv("AGMV_DEVICES");
+	if (!n && e) n = (unsigned)atoi(e);
+	return n ? n : 1;
+}
+
+/* host threads of the pipelines (BMP parse, LZ, BMP export): what the caller asked for, else the cores this process may
+   use -- the online count, cut to the cgroup's CPU quota where there is one (a container's share of a big host) */
 static unsigned lz_threads(void)
 {
 	unsigned n = g_lz_threads;
 	const char* e = getenv("AGMV_LZ_THREADS");
 	if (!n && e) n = (unsigned)atoi(e);
-	if (!n) { long c = sysconf(_SC_NPROCESSORS_ONLN); n = c > 0 ? (unsigned)c : 1; }
+	if (!n) {
+		long c = sysconf(_SC_NPROCESSORS_ONLN);
+		FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r");
+		n = c > 0 ? (unsigned)c : 1;
+		if (f) {
+			long long quota = 0, period = 0;
+			if (fscanf(f, "%lld %lld", &quota, &period) == 2 && quota > 0 && period > 0) {
+				unsigned q = (unsigned)((quota + period - 1) / period);
+				if (q >= 1 && q < n) n = q;
+			}
+			fclose(f);
+		}
+	}
 	return n > 64 ? 64 : n;
 }
 
@@ -176,7 +205,7 @@ int AGMV_DecodeAudioChunk(FILE* f, AGMV* a)
 /* chunk framing around an already compressed payload, reference src/agmv_encode.c:549-550,
    567-585, 622-624: 'AGFC', frame number, usize, csize, csize payload bytes, 8 x 0xFF.
    (the reference writes the flushed partial byte and then overwrites it with the first 0xFF) */
-static void write_frame_chunk(FILE* f, u32 frame_no, u32 usize, u32 csize, const u8* payload)
+void agmv_write_frame_chunk(FILE* f, u32 frame_no, u32 usize, u32 csize, const u8* payload)
 {
 	static const u8 guard[8] = {0xff, 0xff, 0xff, 0xff, 0xff, 0xff, 0xff, 0xff};
 	AGMV_WriteFourCC(f, 'A', 'G', 'F', 'C');
@@ -222,7 +251,7 @@ void AGMV_EncodeFrame(FILE* file, AGMV* a, u32* img_data)
 	/* LZ77 peeks one byte past the stream (:222): hand it the byte the persistent buffer holds there */
 	csize = AGMV_GetCompression(a) == AGMV_LZSS_COMPRESSION ? agmv_lzss_mem(a->bitstream->data, usize, comp)
 	                                                        : agmv_lz77_mem(a->bitstream->data, usize, comp);
-	write_frame_chunk(file, a->frame_count + 1, usize, csize, comp);
+	agmv_write_frame_chunk(file, a->frame_count + 1, usize, csize, comp);
 
 	if (is_i)                                                          /* :626-630 */
 		for (i = 0; i < npx; i++) { a->iframe_entries[i].pal_num = (u8)(ient[i] >> 8); a->iframe_entries[i].index = (u8)ient[i]; }
@@ -399,201 +428,31 @@ void AGMV_AssembleIFrameBitstream(AGMV* a, AGMV_ENTRY* e) { assemble_via_gpu(a, 
 void AGMV_AssemblePFrameBitstream(AGMV* a, AGMV_ENTRY* e) { assemble_via_gpu(a, e, 0); }
 
 /* ------------------------------------------------------------------------------------------
- * sequence encoders
+ * sequence encoders: the drivers decide WHICH frames are encoded (PDIFS schedules, frame skipping), the pipelined engine
+ * of agmv_pipeline.c loads, encodes, compresses and writes them
  * ------------------------------------------------------------------------------------------ */
-typedef struct lzjob {
-	const u8* in; uint32_t n; u8* out; u32 csize; int lz77; u8 saved;
-} lzjob;
+static int is_gba(AGMV_OPT o) { return o == AGMV_OPT_GBA_I || o == AGMV_OPT_GBA_II || o == AGMV_OPT_GBA_III; }
 
-typedef struct lzpool { lzjob* jobs; unsigned count; unsigned next; pthread_mutex_t mu; } lzpool;
-
-static void* lz_worker(void* arg)
+static agmv_seq* seq_open(AGMV* a, FILE* file, const char* dir, const char* base, AGMV_OPT opt, int audio_chunks, int use_interp)
 {
-	lzpool* p = (lzpool*)arg;
-	for (;;) {
-		unsigned k;
-		pthread_mutex_lock(&p->mu);
-		k = p->next++;
-		pthread_mutex_unlock(&p->mu);
-		if (k >= p->count) break;
-		p->jobs[k].csize = p->jobs[k].lz77 ? agmv_lz77_mem(p->jobs[k].in, p->jobs[k].n, p->jobs[k].out)
-		                                   : agmv_lzss_mem(p->jobs[k].in, p->jobs[k].n, p->jobs[k].out);
-	}
-	return NULL;
+	uint32_t pal[512];
+	int i, sw = 0, sh = 0;
+	const int m512 = mode512_of(opt);
+	if (is_gba(opt)) { sw = AGMV_GBA_W; sh = AGMV_GBA_H; }
+	if (opt == AGMV_OPT_NDS) { sw = AGMV_NDS_W; sh = AGMV_NDS_H; }
+	for (i = 0; i < 256; i++) { pal[i] = (uint32_t)a->header.palette0[i]; pal[256 + i] = m512 ? (uint32_t)a->header.palette1[i] : 0; }
+	return agmv_seq_open(a, file, dir, base, sw, sh, m512, AGMV_GetCompression(a) != AGMV_LZSS_COMPRESSION, audio_chunks, use_interp,
+	                     batch_frames((size_t)AGMV_GetWidth(a) * AGMV_GetHeight(a)), devices(), lz_threads(), pal);
 }
 
-static void run_lz(lzjob* jobs, unsigned count)
-{
-	lzpool p;
-	pthread_t th[64];
-	unsigned nt = lz_threads(), t;
-	if (nt > count) nt = count;
-	p.jobs = jobs; p.count = count; p.next = 0;
-	pthread_mutex_init(&p.mu, NULL);
-	for (t = 1; t < nt; t++) pthread_create(&th[t], NULL, lz_worker, &p);
-	lz_worker(&p);
-	for (t = 1; t < nt; t++) pthread_join(th[t], NULL);
-	pthread_mutex_destroy(&p.mu);
-}
-
-typedef struct seq {                       /* one open sequence encode */
-	AGMV* a;
-	FILE* file;
-	const char* dir; const char* base;
-	AGMV_OPT opt;
-	int scale_w, scale_h;                  /* 0 = no scaling */
-	uint32_t w, h;                         /* encoded frame size */
-	int audio_chunks;                      /* write an AGAC chunk after every frame */
-	/* batch state */
-	unsigned cap, n;
-	uint32_t* d_frames; uint8_t* d_out; uint32_t* d_sizes; uint16_t* d_ient; uint32_t* d_tmp[2];
-	uint32_t* h_stage;                     /* one frame, packed */
-	u32 frames_written;
-	u8 lz77_tail;                          /* byte the persistent bitstream buffer holds behind the previous frames */
-	u8* persist; size_t persist_len;       /* emulation of agmv->bitstream->data for LZ77's one-past-the-end read */
-} seq;
-
-static void frame_path(char* out, size_t cap, const char* dir, const char* base, long idx)
-{
-	if (dir[0] != 'c' || dir[1] != 'u' || dir[2] != 'r') snprintf(out, cap, "%s/%s%ld.bmp", dir, base, idx);
-	else snprintf(out, cap, "%s%ld.bmp", base, idx);                /* "cur..." = current directory, :2373-2378 */
-}
-
-/* load source frame `idx` as the encoder sees it: BMP -> 0x00RRGGBB, optional GBA/NDS nearest scale, then the
-   first w*h pixels read linearly (the reference reads a 121x81 scaled image as 120x80) */
-static void load_source(seq* s, long idx, uint32_t* dst)
-{
-	char path[4096];
-	uint32_t *pix = NULL, w = 0, h = 0;
-	size_t need = (size_t)s->w * s->h, have;
-	frame_path(path, sizeof(path), s->dir, s->base, idx);
-	if (agmv_bmp_load(path, &pix, &w, &h) != NO_ERR) { fprintf(stderr, "libagmv(amd): cannot read frame %s\n", path); abort(); }
-	if (s->scale_w) {
-		uint32_t nw, nh;
-		uint32_t* sc = agmv_scale_nearest(pix, w, h, ((float)s->scale_w / w) + 0.001f, ((float)s->scale_h / h) + 0.001f, &nw, &nh);
-		free(pix); pix = sc; w = nw; h = nh;
-	}
-	have = (size_t)w * h;
-	memcpy(dst, pix, (have < need ? have : need) * 4);
-	if (have < need) memset(dst + have, 0, (need - have) * 4);
-	free(pix);
-}
-
-static void seq_open(seq* s, AGMV* a, FILE* file, const char* dir, const char* base, AGMV_OPT opt, int audio_chunks)
-{
-	size_t npx, stride;
-	memset(s, 0, sizeof(*s));
-	s->a = a; s->file = file; s->dir = dir; s->base = base; s->opt = opt; s->audio_chunks = audio_chunks;
-	if (opt == AGMV_OPT_GBA_I || opt == AGMV_OPT_GBA_II || opt == AGMV_OPT_GBA_III) { s->scale_w = AGMV_GBA_W; s->scale_h = AGMV_GBA_H; }
-	if (opt == AGMV_OPT_NDS) { s->scale_w = AGMV_NDS_W; s->scale_h = AGMV_NDS_H; }
-	s->w = (uint32_t)AGMV_GetWidth(a); s->h = (uint32_t)AGMV_GetHeight(a);
-	npx = (size_t)s->w * s->h; stride = agmv_hip_max_usize(s->w, s->h, 1);
-	s->cap = batch_frames();
-	s->d_frames = (uint32_t*)agmv_hip_malloc(npx * 4 * s->cap);
-	s->d_out = (uint8_t*)agmv_hip_malloc(stride * s->cap);
-	s->d_sizes = (uint32_t*)agmv_hip_malloc(4 * (size_t)s->cap);
-	s->d_ient = (uint16_t*)agmv_hip_malloc(npx * 2);
-	s->d_tmp[0] = (uint32_t*)agmv_hip_malloc(npx * 4);
-	s->d_tmp[1] = (uint32_t*)agmv_hip_malloc(npx * 4);
-	s->h_stage = (uint32_t*)malloc(npx * 4);
-	s->persist_len = stride + 64;
-	s->persist = (u8*)calloc(s->persist_len, 1);
-	if (!s->d_frames || !s->d_out || !s->d_sizes || !s->d_ient || !s->d_tmp[0] || !s->d_tmp[1]) agmv_die("device allocation");
-	agmv_hip_memset(s->d_ient, 0, npx * 2);
-	use_palette(a->header.palette0, a->header.palette1, mode512_of(opt));
-}
-
-/* encode + compress + write the frames collected so far */
-static void seq_flush(seq* s)
-{
-	const size_t stride = agmv_hip_max_usize(s->w, s->h, 1);
-	const int lz77 = AGMV_GetCompression(s->a) != AGMV_LZSS_COMPRESSION;
-	uint32_t* sizes;
-	u8 *raw, *comp;
-	lzjob* jobs;
-	size_t total = 0, off = 0, coff = 0;
-	unsigned k;
-	if (!s->n) return;
-	if (agmv_hip_encode_frames_dev(ctx(), s->d_frames, s->n, s->w, s->h, (uint32_t)s->a->frame_count, s->d_out, stride, s->d_sizes,
-	                               s->d_ient, NULL) || agmv_hip_check(g_ctx, NULL))
-		agmv_die("batch encode");
-	sizes = (uint32_t*)malloc(4 * (size_t)s->n);
-	agmv_hip_memcpy_d2h(sizes, s->d_sizes, 4 * (size_t)s->n);
-	for (k = 0; k < s->n; k++) total += sizes[k];
-	raw = (u8*)malloc(total + s->n + 16);              /* +1 per frame: LZ77's one-past-the-end byte */
-	comp = (u8*)malloc(total * 4 + 64 * (size_t)s->n + 64);
-	jobs = (lzjob*)calloc(s->n, sizeof(lzjob));
-	for (k = 0; k < s->n; k++) {
-		if (agmv_hip_memcpy_d2h(raw + off, s->d_out + (size_t)k * stride, sizes[k])) agmv_die("bitstream download");
-		/* the reference compresses agmv->bitstream->data in place, so the byte behind the stream is whatever an
-		   earlier, longer frame left there (LZ77 reads it, src/agmv_encode.c:222) */
-		raw[off + sizes[k]] = sizes[k] < s->persist_len ? s->persist[sizes[k]] : 0;
-		memcpy(s->persist, raw + off, sizes[k] < s->persist_len ? sizes[k] : s->persist_len);
-		jobs[k].in = raw + off; jobs[k].n = sizes[k]; jobs[k].out = comp + coff; jobs[k].lz77 = lz77;
-		off += sizes[k] + 1;
-		coff += (size_t)sizes[k] * 4 + 64;
-	}
-	run_lz(jobs, s->n);
-	for (k = 0; k < s->n; k++) {
-		write_frame_chunk(s->file, s->a->frame_count + 1, sizes[k], jobs[k].csize, jobs[k].out);
-		if (s->audio_chunks) AGMV_EncodeAudioChunk(s->file, s->a);
-		s->a->frame_count++;
-		s->frames_written++;
-	}
-	s->n = 0;
-	free(jobs); free(comp); free(raw); free(sizes);
-}
-
-/* append one encoded frame: source `a`, or the PDIFS midpoint of sources a and b (b >= 0) */
-static void seq_push(seq* s, long a, long b)
-{
-	const size_t npx = (size_t)s->w * s->h;
-	uint32_t* dst = s->d_frames + (size_t)s->n * npx;
-	if (b < 0) {
-		load_source(s, a, s->h_stage);
-		if (agmv_hip_memcpy_h2d(dst, s->h_stage, npx * 4)) agmv_die("frame upload");
-	} else {
-		load_source(s, a, s->h_stage);
-		if (agmv_hip_memcpy_h2d(s->d_tmp[0], s->h_stage, npx * 4)) agmv_die("frame upload");
-		load_source(s, b, s->h_stage);
-		if (agmv_hip_memcpy_h2d(s->d_tmp[1], s->h_stage, npx * 4)) agmv_die("frame upload");
-		if (agmv_hip_interp_dev(ctx(), dst, s->d_tmp[0], s->d_tmp[1], npx, NULL)) agmv_die("interp");   /* AGMV_InterpFrame */
-	}
-	if (++s->n == s->cap) seq_flush(s);
-}
-
-static void seq_close(seq* s)
-{
-	seq_flush(s);
-	agmv_hip_free(s->d_frames); agmv_hip_free(s->d_out); agmv_hip_free(s->d_sizes); agmv_hip_free(s->d_ient);
-	agmv_hip_free(s->d_tmp[0]); agmv_hip_free(s->d_tmp[1]);
-	free(s->h_stage); free(s->persist);
-}
-
-/* pass 1 of the palette build on the GPU: histogram of AGMV_QuantizeColor codes of every source frame
-   at its ORIGINAL size (the reference histograms before scaling, src/agmv_encode.c:2371-2397) */
+/* pass 1 of the palette build on the GPU (histogram), pick on the host */
 static void build_palette_from_frames(const char* dir, const char* base, u32 start, u32 end, u32 size, AGMV_QUALITY quality,
                                       AGMV_OPT opt, u32* p0, u32* p1)
 {
-	uint32_t *d_hist = (uint32_t*)agmv_hip_malloc(4u << 19), *d_pix = NULL, *hist = (uint32_t*)malloc(4u << 19);
-	size_t d_cap = 0;
-	u32 i;
-	if (!d_hist) agmv_die("device allocation");
-	agmv_hip_memset(d_hist, 0, 4u << 19);
-	for (i = start; i <= end; i++) {
-		char path[4096];
-		uint32_t *pix = NULL, w = 0, h = 0;
-		size_t n;
-		frame_path(path, sizeof(path), dir, base, (long)i);
-		if (agmv_bmp_load(path, &pix, &w, &h) != NO_ERR) { fprintf(stderr, "libagmv(amd): cannot read frame %s\n", path); abort(); }
-		n = (size_t)w * h < size ? (size_t)w * h : size;
-		if (n > d_cap) { agmv_hip_free(d_pix); d_pix = (uint32_t*)agmv_hip_malloc(n * 4); d_cap = n; if (!d_pix) agmv_die("device allocation"); }
-		if (agmv_hip_memcpy_h2d(d_pix, pix, n * 4) || agmv_hip_histogram_dev(ctx(), d_pix, n, (int)quality, d_hist, NULL)) agmv_die("histogram");
-		free(pix);
-	}
-	if (agmv_hip_memcpy_d2h(hist, d_hist, 4u << 19)) agmv_die("histogram download");
+	uint32_t* hist = (uint32_t*)malloc(4u << 19);
+	agmv_histogram_frames(ctx(), dir, base, start, end, size, (int)quality, lz_threads(), hist);
 	AGMV_BuildPalette(hist, quality, opt, p0, p1);
-	agmv_hip_free(d_hist); agmv_hip_free(d_pix); free(hist);
+	free(hist);
 }
 
 static void dump_gba_header(const char* filename)
@@ -618,7 +477,6 @@ static void dump_gba_header(const char* filename)
 	free(data);
 }
 
-static int is_gba(AGMV_OPT o) { return o == AGMV_OPT_GBA_I || o == AGMV_OPT_GBA_II || o == AGMV_OPT_GBA_III; }
 static int heavy_pdifs(AGMV_OPT o) { return o == AGMV_OPT_I || o == AGMV_OPT_ANIM || o == AGMV_OPT_GBA_I || o == AGMV_OPT_GBA_II; }
 
 static void resize_for_target(AGMV* a, AGMV_OPT opt)
@@ -642,7 +500,8 @@ void AGMV_EncodeAGMV(AGMV* a, const char* filename, const char* dir, const char*
 {
 	u32 p0[256], p1[256], adjusted = end_frame - start_frame, i;
 	FILE* file;
-	seq s;
+	agmv_seq* s;
+	u32 written;
 	f32 rate;
 	(void)frames_per_second;
 	require_bmp(img_type);
@@ -664,17 +523,17 @@ void AGMV_EncodeAGMV(AGMV* a, const char* filename, const char* dir, const char*
 	AGMV_SetICP1(a, p1);
 	AGMV_EncodeHeader(file, a);
 
-	seq_open(&s, a, file, dir, basename, opt, 1);
+	s = seq_open(a, file, dir, basename, opt, 1, 1);
 	for (i = start_frame; i <= end_frame;) {                  /* :2678, :3610-3612 */
 		/* NDS is "light" only for BMP input (:2727 vs :2810) -- BMP is the only input here */
-		if (!heavy_pdifs(opt)) { seq_push(&s, i, -1); seq_push(&s, i + 1, i + 2); seq_push(&s, i + 3, -1); i += 4; }
-		else { seq_push(&s, i, i + 1); i += 2; }
+		if (!heavy_pdifs(opt)) { agmv_seq_push(s, i, -1); agmv_seq_push(s, i + 1, i + 2); agmv_seq_push(s, i + 3, -1); i += 4; }
+		else { agmv_seq_push(s, i, i + 1); i += 2; }
 		if (i + 4 >= end_frame) break;
 	}
-	seq_close(&s);
+	written = agmv_seq_close(s);
 
 	fseek(file, 4, SEEK_SET);                                 /* :3615-3620 */
-	AGMV_WriteLong(file, s.frames_written);
+	AGMV_WriteLong(file, written);
 	fseek(file, 18, SEEK_SET);
 	rate = (f32)adjusted / (AGMV_GetNumberOfFrames(a) + 1);
 	AGMV_WriteLong(file, (u32)round(AGMV_GetFramesPerSecond(a) * rate));
@@ -690,7 +549,7 @@ void AGMV_EncodeFullAGMV(AGMV* a, const char* filename, const char* dir, const c
 {
 	u32 p0[256], p1[256], i;
 	FILE* file;
-	seq s;
+	agmv_seq* s;
 	(void)frames_per_second;
 	require_bmp(img_type);
 	AGMV_SetOPT(a, opt);
@@ -703,9 +562,9 @@ void AGMV_EncodeFullAGMV(AGMV* a, const char* filename, const char* dir, const c
 	AGMV_SetICP0(a, p0);
 	AGMV_SetICP1(a, p1);
 	AGMV_EncodeHeader(file, a);
-	seq_open(&s, a, file, dir, basename, opt, AGMV_GetTotalAudioDuration(a) != 0);
-	for (i = start_frame; i <= end_frame; i++) seq_push(&s, i, -1);
-	seq_close(&s);
+	s = seq_open(a, file, dir, basename, opt, AGMV_GetTotalAudioDuration(a) != 0, 0);
+	for (i = start_frame; i <= end_frame; i++) agmv_seq_push(s, i, -1);
+	(void)agmv_seq_close(s);
 	fclose(file);
 	DestroyAGMV(a);
 	if (is_gba(opt)) dump_gba_header(filename);
@@ -719,7 +578,10 @@ void AGMV_EncodeVideo(const char* filename, const char* dir, const char* basenam
 	AGMV* a = CreateAGMV(end_frame - start_frame, width, height, frames_per_second);
 	u32 p0[256], p1[256], i;
 	FILE* file;
-	seq s;
+	agmv_seq* s;
+	u32 written;
+	int sw = 0, sh = 0;
+	uint32_t ew, eh;
 	f32 rate, len;
 	size_t npx;
 	u32 *fa, *fb;
@@ -740,28 +602,31 @@ void AGMV_EncodeVideo(const char* filename, const char* dir, const char* basenam
 	AGMV_SetICP0(a, p0);
 	AGMV_SetICP1(a, p1);
 	AGMV_EncodeHeader(file, a);
-	seq_open(&s, a, file, dir, basename, opt, 0);
-	npx = (size_t)s.w * s.h;
+	s = seq_open(a, file, dir, basename, opt, 0, 1);
+	if (is_gba(opt)) { sw = AGMV_GBA_W; sh = AGMV_GBA_H; }
+	if (opt == AGMV_OPT_NDS) { sw = AGMV_NDS_W; sh = AGMV_NDS_H; }
+	ew = (uint32_t)AGMV_GetWidth(a); eh = (uint32_t)AGMV_GetHeight(a);
+	npx = (size_t)ew * eh;
 	fa = (u32*)malloc(npx * sizeof(u32)); fb = (u32*)malloc(npx * sizeof(u32)); tmp = (uint32_t*)malloc(npx * 4);
 	for (i = start_frame; i <= end_frame;) {
 		long x = heavy_pdifs(opt) ? (long)i : (long)i + 1;   /* pair whose similarity decides */
 		size_t k;
 		f32 ratio;
-		load_source(&s, x, tmp); for (k = 0; k < npx; k++) fa[k] = tmp[k];
-		load_source(&s, x + 1, tmp); for (k = 0; k < npx; k++) fb[k] = tmp[k];
-		ratio = AGMV_CompareFrameSimilarity(fa, fb, s.w, s.h);
+		agmv_load_source(dir, basename, x, sw, sh, ew, eh, tmp); for (k = 0; k < npx; k++) fa[k] = tmp[k];
+		agmv_load_source(dir, basename, x + 1, sw, sh, ew, eh, tmp); for (k = 0; k < npx; k++) fb[k] = tmp[k];
+		ratio = AGMV_CompareFrameSimilarity(fa, fb, ew, eh);
 		if (ratio >= AGMV_GetLeniency(a)) {
-			if (!heavy_pdifs(opt)) { seq_push(&s, i, -1); seq_push(&s, i + 1, i + 2); seq_push(&s, i + 3, -1); i += 4; }
-			else { seq_push(&s, i, i + 1); i += 2; }
-		} else { seq_push(&s, i, -1); i += 1; }
+			if (!heavy_pdifs(opt)) { agmv_seq_push(s, i, -1); agmv_seq_push(s, i + 1, i + 2); agmv_seq_push(s, i + 3, -1); i += 4; }
+			else { agmv_seq_push(s, i, i + 1); i += 2; }
+		} else { agmv_seq_push(s, i, -1); i += 1; }
 		if (i + 4 >= end_frame) break;
 	}
-	seq_close(&s);
+	written = agmv_seq_close(s);
 	free(fa); free(fb); free(tmp);
 	fseek(file, 4, SEEK_SET);                                 /* :2225-2231 */
-	AGMV_WriteLong(file, s.frames_written);
+	AGMV_WriteLong(file, written);
 	fseek(file, 18, SEEK_SET);
-	rate = (f32)s.frames_written / AGMV_GetNumberOfFrames(a);
+	rate = (f32)written / AGMV_GetNumberOfFrames(a);
 	AGMV_WriteLong(file, (u32)round(AGMV_GetFramesPerSecond(a) * rate));
 	fclose(file);
 	DestroyAGMV(a);
@@ -773,25 +638,19 @@ void AGMV_EncodeVideo(const char* filename, const char* dir, const char* basenam
  * frame by frame into ONE persistent buffer (so the stale-tail semantics hold), the GPU parses and
  * reconstructs whole batches, frames are exported as quick_export_<n>.bmp in the CWD.
  * ------------------------------------------------------------------------------------------ */
-static size_t scan_fourcc(const u8* d, size_t len, size_t pos, const char* cc)
-{
-	while (pos + 4 <= len) {
-		if (memcmp(d + pos, cc, 4) == 0) return pos;
-		pos++;
-	}
-	return len;
-}
-
 static int decode_file(const char* filename, u8 img_type)
 {
 	FILE* f = fopen(filename, "rb");
 	AGMV hdr_obj;
-	u8 *file, *persist, *slab;
+	u8* file;
 	long flen;
-	size_t pos, npx, cap, stride, got;
-	uint32_t w, h, nframes, ver, done = 0, *bpos, *out, *prev = NULL, *prev_i = NULL;
-	unsigned batch = batch_frames();
-	int err, has_audio;
+	size_t pos, got, npx;
+	uint32_t w, h;
+	unsigned cap;
+	int err, m512;
+	agmv_hip_ctx* c;
+	uint32_t pal[512];
+	int i;
 	if (!f) return FILE_NOT_FOUND_ERR;
 	if (img_type != AGMV_IMG_BMP) { fclose(f); require_bmp(img_type); }
 	memset(&hdr_obj, 0, sizeof(hdr_obj.header));
@@ -800,53 +659,28 @@ static int decode_file(const char* filename, u8 img_type)
 	pos = (size_t)ftell(f);
 	fseek(f, 0, SEEK_END); flen = ftell(f); fseek(f, 0, SEEK_SET);
 	file = (u8*)malloc((size_t)flen + 16);
+	if (!file) { fclose(f); return MEMORY_CORRUPTION_ERR; }
 	got = fread(file, 1, (size_t)flen, f);
 	fclose(f);
 	memset(file + got, 0, 16);
 	w = (uint32_t)hdr_obj.header.width; h = (uint32_t)hdr_obj.header.height;
-	nframes = (uint32_t)hdr_obj.header.num_of_frames; ver = hdr_obj.header.version;
-	has_audio = hdr_obj.header.total_audio_duration != 0;
-	if (w == 0 || h == 0 || (w & 3) || (h & 3)) { free(file); return INVALID_HEADER_FORMATTING_ERR; }
+	if (bad_geometry(w, h)) { free(file); return INVALID_HEADER_FORMATTING_ERR; }
 	npx = (size_t)w * h;
-	use_palette(hdr_obj.header.palette0, hdr_obj.header.palette1, ver == 1 || ver == 3);
-	cap = npx * 33 / 16 + 4096;                           /* persistent decompression buffer, zero-initialised */
-	persist = (u8*)calloc(cap, 1);
-	stride = (cap + 255) & ~(size_t)255;
-	slab = (u8*)malloc(stride * batch);
-	bpos = (uint32_t*)malloc(4 * (size_t)batch);
-	out = (uint32_t*)malloc(npx * 4 * batch);
-	while (done < nframes) {
-		unsigned n = 0, k;
-		while (n < batch && done + n < nframes) {
-			size_t c = scan_fourcc(file, got, pos, "AGFC"), used = 0;
-			uint32_t usize, csize;
-			if (c + 16 > got) break;
-			usize = file[c + 8] | file[c + 9] << 8 | file[c + 10] << 16 | (uint32_t)file[c + 11] << 24;
-			csize = file[c + 12] | file[c + 13] << 8 | file[c + 14] << 16 | (uint32_t)file[c + 15] << 24;
-			bpos[n] = agmv_lz_decode_mem((int)ver, file + c + 16, got - (c + 16), usize, csize, persist, cap, &used);
-			memcpy(slab + (size_t)n * stride, persist, (size_t)bpos[n] + 16 < stride ? (size_t)bpos[n] + 16 : stride);
-			pos = c + 16 + used;
-			if (has_audio) {                              /* AGMV_FindNextAudioChunk + skip */
-				size_t ac = scan_fourcc(file, got, pos, "AGAC");
-				if (ac + 8 <= got) pos = ac + 8 + (file[ac + 4] | file[ac + 5] << 8 | file[ac + 6] << 16 | (size_t)file[ac + 7] << 24);
-			}
-			n++;
-		}
-		if (!n) break;
-		if (agmv_hip_decode_frames(ctx(), slab, stride, bpos, n, w, h, done, out, prev, prev_i)) agmv_die("batch decode");
-		for (k = 0; k < n; k++) {
-			char name[64];
-			snprintf(name, sizeof(name), "quick_export_%lu.bmp", ++g_export_count);   /* AGIDL_QuickExport naming */
-			agmv_bmp_save(name, out + (size_t)k * npx, w, h);
-		}
-		/* decoder state for the next batch: img_data = last frame, iframe = last I-frame */
-		if (!prev) { prev = (uint32_t*)malloc(npx * 4); prev_i = (uint32_t*)calloc(npx, 4); }
-		for (k = 0; k < n; k++) if (((done + k) & 3u) == 0) memcpy(prev_i, out + (size_t)k * npx, npx * 4);
-		memcpy(prev, out + (size_t)(n - 1) * npx, npx * 4);
-		done += n;
+	m512 = hdr_obj.header.version == 1 || hdr_obj.header.version == 3;
+	if (!g_ctx) { const char* e = getenv("AGMV_DEVICE"); g_ctx = agmv_hip_create(e ? atoi(e) : 0); }
+	c = g_ctx;
+	if (!c) { free(file); return gpu_failed("cannot open the GPU"); }
+	for (i = 0; i < 256; i++) { pal[i] = (uint32_t)hdr_obj.header.palette0[i]; pal[256 + i] = m512 ? (uint32_t)hdr_obj.header.palette1[i] : 0; }
+	if (!(g_pal_mode == m512 && memcmp(pal, g_pal, sizeof(pal)) == 0)) {
+		if (agmv_hip_set_palette(c, pal, pal + 256, m512, NULL) || agmv_hip_sync()) { free(file); return gpu_failed("palette upload"); }
+		memcpy(g_pal, pal, sizeof(pal));
+		g_pal_mode = m512;
 	}
-	free(prev); free(prev_i); free(out); free(bpos); free(slab); free(persist); free(file);
-	return NO_ERR;
+	cap = batch_frames(npx);
+	err = agmv_decode_stream(c, file, got, pos, w, h, (uint32_t)hdr_obj.header.num_of_frames, hdr_obj.header.version,
+	                         hdr_obj.header.total_audio_duration != 0, cap, lz_threads(), &g_export_count);
+	free(file);
+	return err;
 }
 
 int AGMV_DecodeVideo(const char* filename, u8 img_type) { return decode_file(filename, img_type); }

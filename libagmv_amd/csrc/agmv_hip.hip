@@ -2311,6 +2311,56 @@ extern "C" int agmv_hip_histogram_dev(agmv_hip_ctx* c, const uint32_t* d_pix, si
 	return 0;
 }
 
+// ---- streams, pinned staging and asynchronous copies for C hosts (the pipelined drivers of agmv_pipeline.c) ----
+extern "C" void* agmv_hip_stream_create(agmv_hip_ctx* c)
+{
+	if (need_ctx(c, false)) return nullptr;
+	hipStream_t s = nullptr;
+	CKP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+	return (void*)s;
+}
+extern "C" void agmv_hip_stream_destroy(agmv_hip_ctx* c, void* stream)
+{
+	if (!c || !stream) return;
+	(void)hipSetDevice(c->device);
+	(void)hipStreamDestroy((hipStream_t)stream);
+}
+extern "C" int agmv_hip_stream_sync(agmv_hip_ctx* c, void* stream)
+{
+	if (need_ctx(c, false)) return -1;
+	CK(hipStreamSynchronize((hipStream_t)stream));
+	return 0;
+}
+extern "C" void* agmv_hip_host_alloc(size_t bytes)
+{
+	void* p = nullptr;
+	if (hipHostMalloc(&p, bytes, hipHostMallocPortable) != hipSuccess) { snprintf(g_err, sizeof(g_err), "agmv_hip: hipHostMalloc(%zu) failed", bytes); return nullptr; }
+	return p;
+}
+extern "C" void agmv_hip_host_free(void* h) { if (h) (void)hipHostFree(h); }
+extern "C" void* agmv_hip_malloc_on(agmv_hip_ctx* c, size_t bytes)
+{
+	if (need_ctx(c, false)) return nullptr;
+	void* p = nullptr;
+	if (hipMalloc(&p, bytes) != hipSuccess) { snprintf(g_err, sizeof(g_err), "agmv_hip: hipMalloc(%zu) failed on device %d", bytes, c->device); return nullptr; }
+	return p;
+}
+extern "C" void agmv_hip_free_on(agmv_hip_ctx* c, void* d) { if (c && d) { (void)hipSetDevice(c->device); (void)hipFree(d); } }
+extern "C" int agmv_hip_memcpy_async(agmv_hip_ctx* c, void* dst, const void* src, size_t n, int kind, void* stream)
+{
+	if (need_ctx(c, false)) return -1;
+	const hipMemcpyKind k = kind == 0 ? hipMemcpyHostToDevice : (kind == 1 ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice);
+	CK(hipMemcpyAsync(dst, src, n, k, (hipStream_t)stream));
+	return 0;
+}
+extern "C" int agmv_hip_memset_async(agmv_hip_ctx* c, void* d, int v, size_t n, void* stream)
+{
+	if (need_ctx(c, false)) return -1;
+	CK(hipMemsetAsync(d, v, n, (hipStream_t)stream));
+	return 0;
+}
+extern "C" int agmv_hip_ctx_device(agmv_hip_ctx* c) { return c ? c->device : -1; }
+
 extern "C" void* agmv_hip_malloc(size_t bytes)
 {
 	void* p = nullptr;

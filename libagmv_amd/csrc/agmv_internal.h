@@ -17,6 +17,7 @@ u32 agmv_lz_decode_mem(int version, const u8* payload, size_t avail, u32 usize, 
    extern/agidl/src/agidl_img_bmp.c:585-655, 1041-1110): rows in FILE order (no flip), B,G,R bytes,
    row padding = width % 4.  Pixels are 4-byte 0x00RRGGBB. */
 int  agmv_bmp_load(const char* path, uint32_t** pix, uint32_t* w, uint32_t* h);
+int  agmv_bmp_load_into(const char* path, uint32_t* dst, size_t max_px, uint32_t* w, uint32_t* h);
 int  agmv_bmp_save(const char* path, const uint32_t* pix, uint32_t w, uint32_t h);
 /* AGIDL_FastScaleBMP(..., AGIDL_SCALE_NEAREST) as the GBA/NDS drivers call it (reference
    src/agmv_encode.c:2707-2721, extern/agidl/src/agidl_imgp_scale.c:262-291) */

@@ -23,68 +23,81 @@
 
 #define WIN 65535
 #define RING 65536
-#define HBITS 16
+#define HBITS 15
 #define HSIZE (1u << HBITS)
 
-/* ---- FIFO buckets of window positions for one gram length ---------------------------------- */
+/* ---- FIFO buckets of window positions for one gram length ------------------------------------
+ * A bucket is a singly linked list through the ring of window slots, oldest first.  Live positions lie within RING of
+ * each other, so links and bucket ends are 16-bit ring SLOTS (position & 0xFFFF) and the absolute position of a slot is
+ * rebuilt from the current position: 4 bytes per slot and 8 per bucket keep the 13 queues of LZSS inside the cache
+ * (3.3 MB + 3.3 MB instead of 12 MB). */
+typedef struct gslot { unsigned short nxt, bkt; } gslot;       /* next newer slot of the bucket; bucket of this slot */
+typedef struct gbkt { int head, tail; } gbkt;                  /* oldest / newest position + 1, 0 = empty */
 typedef struct gq {
 	int L;
-	int* head;          /* [HSIZE] oldest live position + 1, 0 = empty */
-	int* tail;          /* [HSIZE] newest */
-	int* nxt;           /* [RING]  next newer position + 1 in the same bucket */
-	unsigned short* bkt;/* [RING]  bucket of the position stored in the slot */
+	gbkt* b;            /* [HSIZE] */
+	gslot* s;           /* [RING]  */
 } gq;
 
 static void gq_init(gq* q, int L)
 {
 	q->L = L;
-	q->head = (int*)calloc(HSIZE, sizeof(int));
-	q->tail = (int*)calloc(HSIZE, sizeof(int));
-	q->nxt = (int*)calloc(RING, sizeof(int));
-	q->bkt = (unsigned short*)calloc(RING, sizeof(unsigned short));
+	q->b = (gbkt*)calloc(HSIZE, sizeof(gbkt));
+	q->s = (gslot*)calloc(RING, sizeof(gslot));
 }
 
-static void gq_free(gq* q) { free(q->head); free(q->tail); free(q->nxt); free(q->bkt); }
+static void gq_free(gq* q) { free(q->b); free(q->s); }
+
+/* FNV-1a over the gram, folded to HBITS: hash of length L+1 = one step from the hash of length L, so the hashes of all
+   gram lengths at one position cost one pass over at most 15 bytes */
+#define H_INIT 2166136261u
+#define H_STEP(h, byte) (((h) ^ (byte)) * 16777619u)
+#define H_FOLD(h) (((h) ^ ((h) >> 15)) & (HSIZE - 1))
 
 static inline unsigned gram_hash(const u8* p, int L)
 {
-	unsigned h = 2166136261u;
+	unsigned h = H_INIT;
 	int k;
-	for (k = 0; k < L; k++) h = (h ^ p[k]) * 16777619u;
-	return (h ^ (h >> 15)) & (HSIZE - 1);
+	for (k = 0; k < L; k++) h = H_STEP(h, p[k]);
+	return H_FOLD(h);
 }
 
-/* insert position p (its L-gram must lie inside the data); evicts position p-RING first */
-static inline void gq_insert(gq* q, const u8* d, int p, int have_old)
+/* insert position p with its (folded) gram hash; evicts position p-RING first (it is the head of its bucket) */
+static inline void gq_insert_h(gq* q, int p, unsigned h, int have_old)
 {
-	unsigned slot = (unsigned)p & (RING - 1), h;
-	if (have_old) {                              /* slot still holds p-RING: it is the head of its bucket */
-		unsigned ob = q->bkt[slot];
-		if (q->head[ob] == p - RING + 1) {
-			q->head[ob] = q->nxt[slot];
-			if (!q->head[ob]) q->tail[ob] = 0;
+	const unsigned slot = (unsigned)p & (RING - 1);
+	gbkt* nb;
+	if (have_old) {
+		gbkt* ob = &q->b[q->s[slot].bkt];
+		if (ob->head == p - RING + 1) {
+			if (ob->tail == ob->head) ob->head = ob->tail = 0;
+			else ob->head = p - RING + 1 + (int)((q->s[slot].nxt - slot) & (RING - 1));       /* next newer: rebuilt from the slot distance */
 		}
 	}
-	h = gram_hash(d + p, q->L);
-	q->bkt[slot] = (unsigned short)h;
-	q->nxt[slot] = 0;
-	if (q->tail[h]) q->nxt[(unsigned)(q->tail[h] - 1) & (RING - 1)] = p + 1;
-	else q->head[h] = p + 1;
-	q->tail[h] = p + 1;
+	nb = &q->b[h];
+	q->s[slot].bkt = (unsigned short)h;
+	if (nb->tail) q->s[(unsigned)(nb->tail - 1) & (RING - 1)].nxt = (unsigned short)slot;
+	else nb->head = p + 1;
+	nb->tail = p + 1;
 }
 
-/* earliest live position >= lo whose L-gram equals the one at i, or -1 */
-static inline int gq_find(const gq* q, const u8* d, int i, int lo)
+static inline void gq_insert(gq* q, const u8* d, int p, int have_old) { gq_insert_h(q, p, gram_hash(d + p, q->L), have_old); }
+
+/* earliest live position >= lo whose L-gram equals the one at i (hash h), or -1 */
+static inline int gq_find_h(const gq* q, const u8* d, int i, unsigned h, int lo)
 {
-	unsigned h = gram_hash(d + i, q->L);
-	int c = q->head[h];
-	while (c) {
-		int p = c - 1;
+	const gbkt* b = &q->b[h];
+	int p;
+	if (!b->head) return -1;
+	p = b->head - 1;
+	for (;;) {
 		if (p >= lo && memcmp(d + p, d + i, (size_t)q->L) == 0) return p;
-		c = q->nxt[(unsigned)p & (RING - 1)];
+		if (p + 1 == b->tail) return -1;
+		p += (int)((q->s[(unsigned)p & (RING - 1)].nxt - ((unsigned)p & (RING - 1))) & (RING - 1));
 	}
-	return -1;
 }
+
+static inline int gq_find(const gq* q, const u8* d, int i, int lo) { return gq_find_h(q, d, i, gram_hash(d + i, q->L), lo); }
 
 /* ---- token sinks ----------------------------------------------------------------------------*/
 typedef struct sink {
@@ -117,13 +130,21 @@ static u32 lzss_run(const u8* d, int n, sink* s)
 	for (L = 3; L <= 15; L++) gq_init(&q[L], L);
 	while (i < n) {
 		int maxlen = n - i < 15 ? n - i : 15, lo = i - WIN, best = 0, start = 0;
+		unsigned hs[16], h;
 		if (lo < 0) lo = 0;
 		/* make every position < i that owns an L-gram visible */
-		for (; ins < i; ins++)
-			for (L = 3; L <= 15; L++)
-				if (ins + L <= n) gq_insert(&q[L], d, ins, ins >= RING);
+		for (; ins < i; ins++) {
+			const int top = n - ins < 15 ? n - ins : 15, old = ins >= RING;
+			h = H_INIT;
+			for (L = 1; L <= top; L++) {
+				h = H_STEP(h, d[ins + L - 1]);
+				if (L >= 3) gq_insert_h(&q[L], ins, H_FOLD(h), old);
+			}
+		}
+		h = H_INIT;
+		for (L = 1; L <= maxlen; L++) { h = H_STEP(h, d[i + L - 1]); hs[L] = H_FOLD(h); }
 		for (L = maxlen; L >= 3; L--) {
-			int p = gq_find(&q[L], d, i, lo);
+			int p = gq_find_h(&q[L], d, i, hs[L], lo);
 			if (p >= 0) { best = L; start = p; break; }
 		}
 		if (best < 3) {                                    /* literal: flag 1 + 8 bits */

@@ -21,6 +21,9 @@ ABI_SYMBOLS = [
     "agmv_hip_interp_dev", "agmv_hip_histogram_dev", "agmv_hip_check", "agmv_hip_malloc",
     "agmv_hip_free", "agmv_hip_memcpy_h2d", "agmv_hip_memcpy_d2h", "agmv_hip_memset",
     "agmv_hip_sync", "agmv_hip_enable_timing", "agmv_hip_last_kernel_ms",
+    "agmv_hip_stream_create", "agmv_hip_stream_destroy", "agmv_hip_stream_sync", "agmv_hip_host_alloc",
+    "agmv_hip_host_free", "agmv_hip_malloc_on", "agmv_hip_free_on", "agmv_hip_memcpy_async",
+    "agmv_hip_memset_async", "agmv_hip_ctx_device",
 ]
 
 
