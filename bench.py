@@ -16,9 +16,11 @@ Workload (BASELINE.json configs):
                 (512 colours) -- the configuration the roofline target is quoted on
   c2            212 source frames 320x240 -> the 156 encoded frames of AGMV_EncodeAGMV/OPT_III (light PDIFS)
   c5            1280x720 clip (use --frames; 8192 frames need ~70 GB of HBM per GPU)
-Multi-GPU is weak scaling: every rank encodes+decodes its own T-frame clip (frames r*T .. r*T+T-1 of one
-long clip); the only collectives are outside the timed region (the palette histogram all-reduce before,
-the gather of the per-frame bitstreams to rank 0 after).  value = N*T*K / max-over-ranks time.
+Multi-GPU: weak scaling by default -- every rank encodes+decodes its own T-frame clip (frames r*T .. r*T+T-1 of one
+long clip), value = N*T*K / max-over-ranks time.  --scaling strong: ONE T-frame clip (configs 4 and 5) is split over the
+ranks by GOP range (libagmv_amd.shard.gop_ranges), value = T*K / max-over-ranks time.  Either way the only collectives are
+outside the timed region: the palette histogram all-reduce before, and the final gather of the per-frame bitstreams to
+rank 0 after (timed separately: final_gather_ms).
 """
 import argparse
 import ctypes as C
@@ -42,6 +44,8 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="c3", choices=["c3", "c2", "c5"])
     ap.add_argument("--frames", type=int, default=0, help="frames per GPU (default: the workload's)")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak: every rank its own clip of --frames frames; strong: ONE clip of --frames frames split over the ranks by GOP range")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=0, help="frames of the CPU baseline sample")
     return ap.parse_args()
@@ -127,7 +131,10 @@ def main():
     npx = W * H
 
     # ------------------------------------------------------------------ setup (untimed)
+    first_fc = 0
     if wl["pdifs"]:
+        if args.scaling == "strong":
+            raise SystemExit("bench: --scaling strong is for the resident workloads (c3, c5)")
         # AGMV_EncodeAGMV light schedule (reference src/agmv_encode.c:2727-2752): per 4 inputs i..i+3 encode
         # f(i), midpoint(f(i+1), f(i+2)), f(i+3); stop when i+4 >= end.  212 inputs -> 156 encoded frames.
         src = hip.synth_dev(W, H, rank * T + 1, T, device=dev)          # frames numbered 1..T like the BMP files
@@ -142,6 +149,14 @@ def main():
         for k, (a, b) in enumerate(pick):
             frames[k] = src[a - 1] if b < 0 else hip.interp_dev(src[a - 1], src[b - 1])
         hist_src = src
+    elif args.scaling == "strong":
+        from libagmv_amd import shard
+        lo, hi = shard.gop_ranges(T, world)[rank]              # this rank's GOPs of the ONE clip
+        if hi <= lo:
+            raise SystemExit("bench: --scaling strong needs at least one GOP per rank (%d frames, %d ranks)" % (T, world))
+        first_fc = lo
+        frames = hip.synth_dev(W, H, lo, hi - lo, device=dev)
+        hist_src = frames
     else:
         frames = hip.synth_dev(W, H, rank * T, T, device=dev)
         hist_src = frames
@@ -168,9 +183,9 @@ def main():
     dec = torch.empty((n_enc, H, W), dtype=torch.int32, device=dev)
 
     def step():
-        hip.encode_dev(frames, n_enc, W, H, 0, out=out, sizes=sizes)
+        hip.encode_dev(frames, n_enc, W, H, first_fc, out=out, sizes=sizes)
         hip.parse_dev(out, sizes, n_enc, W, H, offsets=offs, nentered=nent)
-        hip.decode_dev(out, sizes, offs, nent, n_enc, W, H, 0, out=dec)
+        hip.decode_dev(out, sizes, offs, nent, n_enc, W, H, first_fc, out=dec)
 
     def barrier():
         torch.cuda.synchronize()
@@ -217,7 +232,7 @@ def main():
         from libagmv_amd import shard
         gathered = shard.gather_bitstreams(dist, sizes, shard.pack_frames(out, sizes), dst=0)
         if rank == 0:
-            assert sum(int(s.numel()) for s, _ in gathered) == world * n_enc
+            assert sum(int(s.numel()) for s, _ in gathered) == (T if args.scaling == "strong" else world * n_enc)
         torch.cuda.synchronize()
         gather_ms = (time.perf_counter() - g0) * 1e3
 
@@ -234,20 +249,21 @@ def main():
                 traffic = None
         res = {
             "metric": "frames/s encode+decode (AGMV hot path: quantise+classify+assemble, parse+reconstruct), synthetic",
-            "value": round(world * n_enc * args.steps / elapsed, 2),
+            "value": round((T if args.scaling == "strong" else world * n_enc) * args.steps / elapsed, 2),
             "unit": "frames/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4),
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": "u8",
             "data": "synthetic",
             "config": {"workload": wl["name"], "frames_per_gpu": int(n_enc), "width": W, "height": H,
                        "palette": "512 colours, reference histogram build (GPU histogram + host pick)",
-                       "parallelism": "frames sharded by GOP range, %d rank(s), no data-path collective" % world,
+                       "parallelism": ("one %d-frame clip split by GOP range over %d rank(s)" % (T, world) if args.scaling == "strong" else
+                                       "%d frames per rank, %d rank(s)" % (int(n_enc), world)) + ", no data-path collective",
                        "mean_usize_bytes": float(usz.mean())},
             "roofline": {"bound": "hbm", "kernel": "k_encode", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,

@@ -67,10 +67,13 @@ def gather_bitstreams(dist, sizes, packed, dst=0):
         for q in reqs:
             q.wait()
         return res
+    reqs = []                                                  # both messages in flight at once; the root has posted every receive
     if sizes.numel():
-        dist.send(sizes, dst=dst)
+        reqs.append(dist.isend(sizes, dst=dst))
     if packed.numel():
-        dist.send(packed, dst=dst)
+        reqs.append(dist.isend(packed, dst=dst))
+    for q in reqs:
+        q.wait()
     return None
 
 
