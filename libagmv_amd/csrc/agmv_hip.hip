@@ -73,14 +73,17 @@ extern "C" const char* agmv_hip_last_error(void) { return g_err; }
 #else
 #define ENC_WAVES_ATTR
 #endif
+#ifndef ENC_ORDER
+#define ENC_ORDER 0           /* ticket -> (tile, GOP): 0 tile-major over all GOPs, 1 GOP-major, 2 tile-major inside bands of ENC_BAND GOPs */
+#endif
+#ifndef ENC_BAND
+#define ENC_BAND 16
+#endif
+#ifndef ENC_PFDEPTH
+#define ENC_PFDEPTH 1         /* items whose pixels are in flight per wave (the loop is unrolled by this many register sets); 2 measured the same as 1 (0.716 vs 0.719 ms per 256 frames): the wait is not the latency of one load */
+#endif
 #ifndef ENC_PFLATE
 #define ENC_PFLATE 3          /* where the next item's pixel loads are issued: 0 behind the look-ups, 1 after emit (ahead of the tile-offset wait), 2 after classify, 3 after the copy-out (measured best: synth 0.730 vs 0.768 ms per 256 frames) */
-#endif
-#ifndef ENC_HDUP
-#define ENC_HDUP 0            /* 1: no look-up for a pixel that equals its left neighbour in the lane's row segment (see the Q phase) */
-#endif
-#ifndef ENC_CC
-#define ENC_CC 0              /* log2 of the slots of the workgroup's colour cache in LDS (0 = no cache; see the Q phase) */
 #endif
 constexpr int ENC_T = ENC_T_OVERRIDE;          // threads per encode workgroup = 4x4 blocks per tile
 constexpr int ENC_WAVES = ENC_T / 64;
@@ -362,14 +365,7 @@ constexpr int C_TTOTAL = C_ARRIVE + DF_SLOTS;                  // [slot]        
 constexpr int C_GBASE = C_TTOTAL + DF_SLOTS;                   // [slot][wave][2]   frame byte offset of the wave, tag
 constexpr int C_TICKET = C_GBASE + DF_SLOTS * ENC_WAVES * 2;   // [slot][2]         ticket of tile sequence number s, s
 constexpr int C_END = C_TICKET + DF_SLOTS * 2;
-constexpr uint32_t CC_SLOTS = ENC_CC ? (1u << ENC_CC) : 0u;
-constexpr uint32_t CC_MUL = 0x9E3779u;                         // odd: colour -> colour * CC_MUL mod 2^24 is a bijection
-constexpr uint32_t CC_SHIFT = 24 - ENC_CC - 2;                 // slot = the top ENC_CC bits of the 24, as a byte offset
-constexpr uint32_t CC_AMASK = (CC_SLOTS - 1u) << 2;
-constexpr uint32_t CC_TMASK = (1u << (24 - ENC_CC)) - 1u;      // tag = the remaining low bits
-constexpr uint32_t CC_VALID = 1u << (24 - ENC_CC);
-static_assert(ENC_CC == 0 || (ENC_CC >= 8 && ENC_CC <= 15), "cache word = valid | tag (24 - ENC_CC bits) | entry (9 bits)");
-constexpr size_t ENC_LDS_EXTRA = 2 * ENC_WAVES * WSLOT + C_END * 4 + CC_SLOTS * 4;
+constexpr size_t ENC_LDS_EXTRA = 2 * ENC_WAVES * WSLOT + C_END * 4;
 
 typedef uint16_t __attribute__((aligned(1))) u16u;          // byte-aligned 16/32-bit LDS stores (DS unaligned mode)
 typedef uint32_t __attribute__((aligned(1))) u32u;
@@ -417,34 +413,20 @@ template <bool M512, bool PFRAME>
 __device__ __forceinline__ void block_tests(const uint32_t (&ep)[8], const uint32_t (&ip)[8], const uint32_t* s_mtx,
                                             uint32_t row0, uint32_t& acc1, uint32_t& acc2, uint32_t& nesc)
 {
-	// All matrix words of the block are requested BEFORE the first one is used (two batches of 16 for a P-frame: the LDS
-	// counter tracks 15 reads): left to itself the compiler keeps two or three reads in flight and waits a dozen times,
-	// and with four waves per SIMD those LDS round trips are exposed.
-	uint32_t wa[8], wb[8], va[8], vb[8];
+	// (requesting all 16 / 32 matrix words before the first use -- 110 VGPRs instead of 96 -- measured the same: 0.723 vs
+	//  0.728 ms per 256 frames; the LDS round trips of one wave are covered by the other three of its SIMD)
 #pragma unroll
 	for (int m = 0; m < 8; m++) {
-		const uint32_t p = ep[m], a5 = (p >> 5) & 0x7ffu, b5 = p >> 21;
-		wa[m] = lds_ld(s_mtx + row0 + a5);
-		wb[m] = lds_ld(s_mtx + row0 + b5);
-	}
-	if (PFRAME) {
-#pragma unroll
-		for (int m = 0; m < 8; m++) {
-			const uint32_t p = ep[m], a5 = (p >> 5) & 0x7ffu, b5 = p >> 21, q = ip[m];
-			va[m] = lds_ld(s_mtx + (q & 0xffffu) * MROW + a5);
-			vb[m] = lds_ld(s_mtx + (q >> 16) * MROW + b5);
-		}
-	}
-	__builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-	for (int m = 0; m < 8; m++) {
-		const uint32_t p = ep[m], bh = p >> 16;
-		acc1 = __builtin_amdgcn_alignbit(wa[m] >> (p & 31u), acc1, 1);
-		acc1 = __builtin_amdgcn_alignbit(wb[m] >> (bh & 31u), acc1, 1);
+		const uint32_t p = ep[m], a5 = (p >> 5) & 0x7ffu, b5 = p >> 21, bh = p >> 16;
+		const uint32_t wa = s_mtx[row0 + a5], wb = s_mtx[row0 + b5];
+		acc1 = __builtin_amdgcn_alignbit(wa >> (p & 31u), acc1, 1);
+		acc1 = __builtin_amdgcn_alignbit(wb >> (bh & 31u), acc1, 1);
 		if (M512) nesc += ((p & 0xffu) >= 127u ? 1u : 0u) + ((bh & 0xffu) >= 127u ? 1u : 0u);
 		if (PFRAME) {
-			acc2 = __builtin_amdgcn_alignbit(va[m] >> (p & 31u), acc2, 1);
-			acc2 = __builtin_amdgcn_alignbit(vb[m] >> (bh & 31u), acc2, 1);
+			const uint32_t q = ip[m];
+			const uint32_t va = s_mtx[(q & 0xffffu) * MROW + a5], vb = s_mtx[(q >> 16) * MROW + b5];
+			acc2 = __builtin_amdgcn_alignbit(va >> (p & 31u), acc2, 1);
+			acc2 = __builtin_amdgcn_alignbit(vb >> (bh & 31u), acc2, 1);
 		}
 	}
 }
@@ -467,10 +449,6 @@ __global__ __launch_bounds__(ENC_T, ENC_WPE) ENC_WAVES_ATTR void k_encode(EncArg
 	uint32_t* s_mtx = (uint32_t*)smem;                         // NROWS * MROW dwords
 	uint8_t* s_stage0 = smem + NROWS * MROW * 4;               // [2][ENC_WAVES] stage slots
 	uint32_t* s_ctl = (uint32_t*)(s_stage0 + 2 * ENC_WAVES * WSLOT);
-#if ENC_CC
-	uint32_t* s_cc = s_ctl + C_END;                            // the colour cache (see the Q phase)
-	for (int i = threadIdx.x; i < (int)CC_SLOTS; i += ENC_T) s_cc[i] = 0;
-#endif
 
 	const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 	const uint32_t npx = A.w * A.h;
@@ -493,8 +471,19 @@ __global__ __launch_bounds__(ENC_T, ENC_WPE) ENC_WAVES_ATTR void k_encode(EncArg
 	// geometry: ONE integer division per wave (of its first block, wave-uniform); lane positions follow by adding and
 	// wrapping at the end of a block row (no per-lane divisions)
 	auto setup = [&](uint32_t t, EncGeo& g) {
+#if ENC_ORDER == 1
+		const uint32_t group = t / A.tpf;                      // GOP-major: consecutive tickets are consecutive tiles of one GOP (adjacent memory)
+		g.tile = t - group * A.tpf;
+#elif ENC_ORDER == 2
+		// bands of ENC_BAND GOPs, tile-major inside a band
+		const uint32_t band = t / (A.tpf * ENC_BAND), r = t - band * (A.tpf * ENC_BAND);
+		const uint32_t gb = A.n_groups - band * ENC_BAND < ENC_BAND ? A.n_groups - band * ENC_BAND : ENC_BAND;   // GOPs in this band
+		g.tile = r / gb;
+		const uint32_t group = band * ENC_BAND + (r - g.tile * gb);
+#else
 		g.tile = t / A.n_groups;
 		const uint32_t group = t - g.tile * A.n_groups;
+#endif
 		g.f_lo = group == 0 ? 0 : (int)(group * 4 - A.phase);
 		g.f_hi = (int)(group * 4 - A.phase) + 4;
 		if (g.f_hi > (int)A.n_frames) g.f_hi = (int)A.n_frames;
@@ -539,20 +528,66 @@ __global__ __launch_bounds__(ENC_T, ENC_WPE) ENC_WAVES_ATTR void k_encode(EncArg
 		}
 	};
 
-	EncGeo g, gn;
-	uint32_t ticket = __builtin_amdgcn_readfirstlane(lds_ld(&s_ctl[C_TICKET]));
-	bool have = ticket < A.total_tiles;
-	if (have) setup(ticket, g);
-	uint32_t seq = 0, it = 0;                                  // tile sequence number, item number (tags / slots)
-	int f = have ? g.f_lo : 0;
+	// Two cursors walk the workgroup's sequence of (tile, frame) items: `cur` is the item being encoded, `pf` the item whose
+	// pixels are requested next, ENC_PFDEPTH items ahead (every item's pixels are in flight for that many item times).  A
+	// cursor that leaves its tile takes the ticket of the next one from the LDS slot of that tile's sequence number; wave 0
+	// draws a tile's ticket when its OWN prefetch cursor enters the tile before it and publishes it behind its next look-ups.
+	struct Cursor { EncGeo g; int f; uint32_t seq; bool have; };
+	Cursor cur, pf;
+	uint32_t tk = 0, tk_seq = 0;
+	bool tk_pending = false;
+	auto draw_ticket = [&](uint32_t for_seq) {
+		if (wave == 0) {
+			if (lane == 0) tk = atomicAdd(A.ctrl, 1u);
+			tk_seq = for_seq; tk_pending = true;
+		}
+	};
+	auto publish_ticket = [&]() {
+		if (wave == 0 && tk_pending) {
+			const uint32_t tkv = __builtin_amdgcn_readfirstlane(tk);
+			if (lane == 0) {
+				uint32_t* tw = &s_ctl[C_TICKET + (tk_seq & (DF_SLOTS - 1)) * 2];
+				lds_st(tw, tkv);
+				asm volatile("" ::: "memory");
+				lds_st(tw + 1, tk_seq);
+			}
+			tk_pending = false;
+		}
+	};
+	auto advance = [&](Cursor& c, bool lead) -> bool {         // to the next item; true when that is the first item of a tile
+		if (c.f + 1 < c.g.f_hi) { c.f++; return false; }
+		if (lead) publish_ticket();                            // wave 0 is about to wait for the ticket it drew itself
+		const uint32_t* tw = &s_ctl[C_TICKET + ((c.seq + 1) & (DF_SLOTS - 1)) * 2];
+		lds_wait(tw + 1, c.seq + 1, 0, A.ctrl, lane);
+		asm volatile("" ::: "memory");
+		const uint32_t nt = __builtin_amdgcn_readfirstlane(lds_ld(tw));
+		c.seq++;
+		c.have = nt < A.total_tiles;
+		if (c.have) {
+			setup(nt, c.g);
+			c.f = c.g.f_lo;
+			if (lead) draw_ticket(c.seq + 1);
+		}
+		return true;
+	};
+	{
+		const uint32_t ticket = __builtin_amdgcn_readfirstlane(lds_ld(&s_ctl[C_TICKET]));
+		cur.seq = 0; cur.f = 0;
+		cur.have = ticket < A.total_tiles;
+		if (cur.have) { setup(ticket, cur.g); cur.f = cur.g.f_lo; }
+	}
+	pf = cur;
+	if (pf.have) draw_ticket(1);
+	uint32_t it = 0;                                           // item number (tags / slots)
 	bool new_tile = true;
 	uint32_t ip[8];                                            // the GOP's I-frame entries of this block, two u16 per register
-	uint4 px[4];
-	if (have) load_frame(g, A.pix + (size_t)f * npx, px);
+	uint4 pxs[ENC_PFDEPTH][4];
+#pragma unroll
+	for (int d = 0; d < ENC_PFDEPTH; d++)
+		if (pf.have) { load_frame(pf.g, A.pix + (size_t)pf.f * npx, pxs[d]); advance(pf, true); }
 	bool have_prev = false;                                    // item it-1: tile, frame, bytes of this wave
 	uint32_t p_tile = 0, p_len = 0;
 	int p_f = 0;
-	uint32_t tk = 0;
 
 #ifdef ENC_PROF
 	uint32_t prof[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -561,7 +596,9 @@ __global__ __launch_bounds__(ENC_T, ENC_WPE) ENC_WAVES_ATTR void k_encode(EncArg
 #else
 #define PSTAMP(k) do { } while (0)
 #endif
-	for (;;) {
+	auto body = [&](uint4 (&px)[4]) -> bool {                 // one item: consumes px and refills it with the item ENC_PFDEPTH ahead
+		EncGeo& g = cur.g;
+		const int f = cur.f;
 		const uint32_t slot = it & (DF_SLOTS - 1), tag = (it + 1) & 0xffffu;
 		const uint32_t pslot = (it - 1) & (DF_SLOTS - 1), ptag = it & 0xffffu;
 		// (L) the look-back of item it-1 is the duty of ONE wave (rotating), done while its own table look-ups are in
@@ -611,12 +648,12 @@ __global__ __launch_bounds__(ENC_T, ENC_WPE) ENC_WAVES_ATTR void k_encode(EncArg
 			wave_copy_own(s_stage0 + (((it - 1) & 1) * ENC_WAVES + wave) * WSLOT, A.out + (size_t)p_f * A.out_stride + base, p_len, lane);
 		};
 
-		if (!have) {                                           // final drain: item it-1 is the last one
+		if (!cur.have) {                                       // final drain: item it-1 is the last one
 			if (have_prev) {
 				if (duty) resolve_prev();
 				copy_out_prev();
 			}
-			break;
+			return false;
 		}
 
 		const bool is_i = ((A.first_fc + f) & 3u) == 0;
@@ -633,34 +670,12 @@ __global__ __launch_bounds__(ENC_T, ENC_WPE) ENC_WAVES_ATTR void k_encode(EncArg
 #pragma unroll
 				for (int m = 0; m < 8; m++) ip[m] = 0;
 			}
-			if (wave == 0 && lane == 0) tk = atomicAdd(A.ctrl, 1u);   // ticket of the NEXT tile, drawn a tile ahead
 		}
-		// ---- next item's pixels (next frame, or the first frame of the NEXT tile, whose ticket was drawn one tile earlier)
-		bool have_next = true;
+		// ---- the pixels of the item ENC_PFDEPTH ahead, into the registers this item's pixels leave
 		auto prefetch_next = [&]() {
 			asm volatile("" ::: "memory");
-			if (new_tile && wave == 0) {                           // publish the next tile's ticket to the other waves
-				const uint32_t tkv = __builtin_amdgcn_readfirstlane(tk);
-				if (lane == 0) {
-					uint32_t* tw = &s_ctl[C_TICKET + ((seq + 1) & (DF_SLOTS - 1)) * 2];
-					lds_st(tw, tkv);
-					asm volatile("" ::: "memory");
-					lds_st(tw + 1, seq + 1);
-				}
-			}
-			if (f + 1 < g.f_hi) {
-				load_frame(g, A.pix + (size_t)(f + 1) * npx, px);
-			} else {
-				const uint32_t* tw = &s_ctl[C_TICKET + ((seq + 1) & (DF_SLOTS - 1)) * 2];
-				lds_wait(tw + 1, seq + 1, 0, A.ctrl, lane);
-				asm volatile("" ::: "memory");
-				const uint32_t nt = __builtin_amdgcn_readfirstlane(lds_ld(tw));
-				have_next = nt < A.total_tiles;
-				if (have_next) {
-					setup(nt, gn);
-					load_frame(gn, A.pix + (size_t)gn.f_lo * npx, px);
-				}
-			}
+			publish_ticket();
+			if (pf.have) { load_frame(pf.g, A.pix + (size_t)pf.f * npx, px); advance(pf, true); }
 		};
 #ifdef ENC_PROF
 		PSTAMP(9);                                             // loop top: bookkeeping, duty status prefetch, I-frame entry plane
@@ -680,49 +695,6 @@ __global__ __launch_bounds__(ENC_T, ENC_WPE) ENC_WAVES_ATTR void k_encode(EncArg
 #else
 #define LUT_OFF(c) lut_offset(c)
 #endif
-#if ENC_CC
-		// Colour cache.  The CU's L1 serves ONE lane per clock once the four lanes of a quad read different addresses
-		// (tools/micro/tcpbench.hip: 64 clocks per look-up instruction, against 16 when every quad reads one address), i.e.
-		// one pixel per clock per CU = 2.2 TB/s of pixels: the look-ups, not HBM, bound the encoder.  So the lanes first
-		// probe a direct-mapped table of (colour -> entry) words in LDS, shared by the workgroup, and only the lanes that miss
-		// go to the global table (EXEC-masked: the L1's time follows the active lanes); they add their colour afterwards.
-		// A slot is ONE 32-bit word {valid, tag, entry}: slot index and tag together are a bijection of the 24-bit colour
-		// (h = colour * odd constant mod 2^24), so a hit is the entry of exactly that colour; a word is read and written
-		// whole, so concurrent waves see either the old or the new pair, never a mixture.  Zeroed at kernel start (a launch
-		// has one palette).
-		uint32_t hh[16];
-		unsigned long long missm[16];
-		{
-			uint32_t cw[16];
-#pragma unroll
-			for (int k = 0; k < 16; k++) {
-				hh[k] = __umul24(pxv[k], CC_MUL);                  // bits 23:0 of the product: a bijection of the colour
-				cw[k] = *(const lds_u32*)((const uint8_t*)s_cc + ((hh[k] >> CC_SHIFT) & CC_AMASK));
-			}
-#pragma unroll
-			for (int k = 0; k < 16; k++) {
-				const bool miss = (cw[k] >> 9) != ((hh[k] & CC_TMASK) | CC_VALID);
-				missm[k] = __ballot(miss);
-				eq[k] = cw[k] & 0x1FFu;
-				if (miss) eq[k] = (uint16_t)__builtin_amdgcn_raw_buffer_load_b16(lut_rs, LUT_OFF(pxv[k]), 0, ENC_LUTAUX);
-			}
-		}
-#elif ENC_HDUP
-		// The CU's L1 serves ONE lane per clock once the four lanes of a quad read different addresses (64 clocks per look-up
-		// instruction; 16 when every quad reads one address; nothing for a lane that is masked off -- tools/micro/tcpbench.hip),
-		// so the look-ups, not HBM, bound the encoder on anything but flat content.  A pixel that equals its left neighbour in
-		// the lane's row segment has the neighbour's entry: its look-up is not issued (EXEC-masked; skipped altogether when no
-		// lane of the wave needs it) and the entry is copied once the neighbour's has landed.  Exact: the table is a function
-		// of the pixel.
-		unsigned long long dupm[12];
-#pragma unroll
-		for (int k = 0; k < 16; k++) {
-			bool dup = false;
-			if (k & 3) { dup = pxv[k] == pxv[k - 1]; dupm[(k >> 2) * 3 + (k & 3) - 1] = __ballot(dup); }
-			eq[k] = 0;
-			if (!dup) eq[k] = (uint16_t)__builtin_amdgcn_raw_buffer_load_b16(lut_rs, LUT_OFF(pxv[k]), 0, ENC_LUTAUX);
-		}
-#else
 #pragma unroll
 		for (int k = 0; k < 16; k++) {
 #ifdef ABL_NOGATHER
@@ -732,7 +704,6 @@ __global__ __launch_bounds__(ENC_T, ENC_WPE) ENC_WAVES_ATTR void k_encode(EncArg
 			else eq[k] = (uint16_t)__builtin_amdgcn_raw_buffer_load_b16(lut_rs, LUT_OFF(pxv[k]), 0, ENC_LUTAUX);
 #endif
 		}
-#endif
 		PSTAMP(0);
 		// issued right BEHIND the look-ups (the memory counter retires in order: ahead of them they would have to land
 		// before the first entry is usable), and before the wait for the entries
@@ -743,17 +714,6 @@ __global__ __launch_bounds__(ENC_T, ENC_WPE) ENC_WAVES_ATTR void k_encode(EncArg
 		__builtin_amdgcn_s_setprio(0);
 #endif
 		PSTAMP(2);
-#if ENC_HDUP
-#pragma unroll
-		for (int k = 0; k < 16; k++)                               // left to right: a run of equal pixels takes the first one's entry
-			if ((k & 3) && __builtin_amdgcn_inverse_ballot_w64(dupm[(k >> 2) * 3 + (k & 3) - 1])) eq[k] = eq[k - 1];
-#endif
-#if ENC_CC
-#pragma unroll
-		for (int k = 0; k < 16; k++)                               // the lanes that missed add {tag, entry} of their colour
-			if (__builtin_amdgcn_inverse_ballot_w64(missm[k]))
-				*(lds_u32*)((uint8_t*)s_cc + ((hh[k] >> CC_SHIFT) & CC_AMASK)) = (((hh[k] & CC_TMASK) | CC_VALID) << 9) | eq[k];
-#endif
 		// [block][pixel] u16 table in the wave's scratch; a lane writes its row: 8 bytes at i*512 + lane*8
 #pragma unroll
 		for (int i = 0; i < 4; i++) {
@@ -887,14 +847,15 @@ __global__ __launch_bounds__(ENC_T, ENC_WPE) ENC_WAVES_ATTR void k_encode(EncArg
 		// ---- next item
 		have_prev = true; p_tile = g.tile; p_f = f; p_len = wtot;
 		it++;
-		if (f + 1 < g.f_hi) {
-			f++; new_tile = false;
-		} else {
-			have = have_next;
-			if (have) { g = gn; f = g.f_lo; }
-			seq++; new_tile = true;
-		}
+		new_tile = advance(cur, false);
+		return true;
+	};
+	for (;;) {
+#pragma unroll
+		for (int d = 0; d < ENC_PFDEPTH; d++)
+			if (!body(pxs[d])) goto done;
 	}
+done:;
 #ifdef ENC_PROF
 	if (lane == 0)
 		for (int k = 0; k < 11; k++) atomicAdd(A.ctrl + 32 + k, k == 10 ? prof[k] : prof[k] >> 6);

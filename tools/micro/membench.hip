@@ -6,6 +6,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 #include <vector>
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
@@ -192,14 +193,16 @@ template <int NG, int AUX, int LANES, uint32_t MASK = 0xFFFFFFFFu, int BUSY = 0,
 	hipLaunchKernelGGL((k_items<NG, AUX, LANES, MASK, BUSY, LATE>), dim3(wg), dim3(256), 0, 0, c->img, 1792u, 1080u, 256u, c->lut, c->sink);
 }
 
-int main()
+int main(int argc, char** argv)
 {
+	// groups: streams | items | busy   (default: all)
+	const char* sel = argc > 1 ? argv[1] : "all";
+	auto want = [&](const char* g) { return !strcmp(sel, "all") || !strcmp(sel, g); };
 	hipDeviceProp_t prop; CK(hipGetDeviceProperties(&prop, 0));
 	const int ncu = prop.multiProcessorCount;
 	const size_t bytes = (size_t)2 << 30;
 	uint32_t *src, *sink; uint16_t* lut;
 	CK(hipMalloc(&src, bytes)); CK(hipMalloc(&sink, 64)); CK(hipMalloc(&lut, (size_t)1 << 29));
-	// data: a smooth gradient (look-ups of neighbouring lanes share table lines), as in the synthetic clip
 	{
 		std::vector<uint32_t> h(bytes / 4);
 		for (size_t i = 0; i < h.size(); i++) { uint32_t x = (uint32_t)(i % 1920), y = (uint32_t)((i / 1920) % 1080), t = (uint32_t)(i / (1920 * 1080)); h[i] = ((x / 8 + 2 * t) & 255) << 16 | ((y / 4 + t) & 255) << 8 | (((x + y) / 16 + 3 * t) & 255); }
@@ -207,22 +210,57 @@ int main()
 	}
 	CK(hipMemset(lut, 1, (size_t)1 << 29));
 	Ctx c{src, bytes, lut, sink, 16, ncu, nullptr};
-	printf("%d CUs; read-only stream of %.1f GB; TB/s by waves per CU (columns)\n", ncu, bytes / 1e9);
 	const int wpcs[] = {4, 8, 16, 24, 32};
+	printf("%d CUs; TB/s by waves per CU (columns)\n", ncu);
 #define ROW(name, fn) do { printf("%-44s", name); for (int w : wpcs) { c.wpc = w; float ms = time_it(fn, &c); printf(" %2d:%5.2f", w, bytes / ms / 1e9); } printf("\n"); fflush(stdout); } while (0)
-	// ---- k_encode-shaped items: 256 frames of 1792 x 1080 (7 items per block row), three kinds of content
-	{
+	if (want("streams")) {
+		printf("-- read-only stream of %.1f GB, D KiB in flight per wave\n", bytes / 1e9);
+		ROW("vgpr D=1 default", (l_stream<1, 0, 0>));
+		ROW("vgpr D=2 default", (l_stream<2, 0, 0>));
+		ROW("vgpr D=4 default", (l_stream<4, 0, 0>));
+		ROW("vgpr D=8 default", (l_stream<8, 0, 0>));
+		ROW("vgpr D=4 nt", (l_stream<4, 2, 0>));
+		ROW("vgpr D=8 nt", (l_stream<8, 2, 0>));
+		ROW("vgpr D=4 sc1 nt", (l_stream<4, 18, 0>));
+		ROW("vgpr D=4 nt + 16 look-ups/lane (linear table)", (l_stream<4, 2, 1>));
+		ROW("lds-dma D=4 R=2 default", (l_lds<4, 2, 0>));
+		ROW("lds-dma D=4 R=3 default", (l_lds<4, 3, 0>));
+		ROW("lds-dma D=4 R=2 nt", (l_lds<4, 2, 2>));
+		ROW("lds-dma D=4 R=3 nt", (l_lds<4, 3, 2>));
+		ROW("lds-dma D=8 R=2 nt", (l_lds<8, 2, 2>));
+	}
+	// ---- k_encode-shaped items: 256 frames of 1792 x 1080 (7 items per block row)
+	if (want("items") || want("busy")) {
 		const uint32_t W = 1792, H = 1080, T = 256;
 		const size_t n = (size_t)W * H * T;
 		uint32_t* img; CK(hipMalloc(&img, n * 4));
 		std::vector<uint32_t> h(n);
 		const size_t ibytes = n * 4;
-		for (int kind = 0; kind < 1; kind++) {
+#define IROW(name, fn) do { printf("%-44s", name); for (int w : wpcs) { c.wpc = w; float ms = time_it(fn, &c); printf(" %2d:%5.2f", w, ibytes / ms / 1e9); } printf("\n"); fflush(stdout); } while (0)
+		for (int kind = 0; kind < 3 && want("items"); kind++) {
+			uint64_t z = 12345;
+			for (size_t i = 0; i < n; i++) {
+				uint32_t x = (uint32_t)(i % W), y = (uint32_t)((i / W) % H), t = (uint32_t)(i / ((size_t)W * H));
+				uint32_t r = (x * 255 / (W - 1) + 2 * t) & 255, g = (y * 255 / (H - 1) + t) & 255, b = ((x + y) / 2 + 3 * t) & 255;
+				uint32_t v = r << 16 | g << 8 | b;
+				if (kind == 0) v = 0x336699;
+				if (kind == 2) { z = z * 6364136223846793005ull + 1442695040888963407ull; v ^= (uint32_t)(z >> 33) & 0x070707u; }
+				h[i] = v;
+			}
+			CK(hipMemcpy(img, h.data(), ibytes, hipMemcpyHostToDevice));
+			c.img = img;
+			printf("-- items, %s (TB/s of pixel bytes)\n", kind == 0 ? "flat" : kind == 1 ? "gradient" : "gradient^noise3");
+			IROW("items nt, no look-ups", (l_items<0, 2, 64>));
+			IROW("items nt, 16 look-ups/lane", (l_items<1, 2, 64>));
+			IROW("items nt, 16 look-ups, table masked to 16 KB", (l_items<1, 2, 64, 0x3FFEu>));
+			IROW("items nt, 16 look-ups, table masked to 2 MB", (l_items<1, 2, 64, 0x1FFFFEu>));
+			IROW("items default policy, 16 look-ups", (l_items<1, 0, 64>));
+		}
+		if (want("busy")) {
 			for (size_t i = 0; i < n; i++) h[i] = 0x336699;
 			CK(hipMemcpy(img, h.data(), ibytes, hipMemcpyHostToDevice));
 			c.img = img;
-			printf("-- items, flat, no look-ups, B dependent VALU ops of busy work per item (TB/s of pixel bytes); early = next loads issued before the work, late = after\n");
-#define IROW(name, fn) do { printf("%-44s", name); for (int w : wpcs) { c.wpc = w; float ms = time_it(fn, &c); printf(" %2d:%5.2f", w, ibytes / ms / 1e9); } printf("\n"); fflush(stdout); } while (0)
+			printf("-- items, flat, no look-ups, B dependent VALU ops of busy work per item; early = next loads issued before the work, late = after\n");
 			IROW("B=0", (l_items<0, 2, 64, 0xFFFFFFFFu, 0, 0>));
 			IROW("B=200 early", (l_items<0, 2, 64, 0xFFFFFFFFu, 200, 0>));
 			IROW("B=200 late", (l_items<0, 2, 64, 0xFFFFFFFFu, 200, 1>));

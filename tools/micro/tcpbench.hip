@@ -1,6 +1,7 @@
 // tools/micro/tcpbench.hip -- cost model of a 16-bit table look-up instruction in the CU's L1 (TCP) on gfx950, measured inside a
 // streaming loop of k_encode's shape (4 x b128 pixel loads + 16 look-ups per wave-item): how the time depends on how the 64 lanes'
-// addresses spread over 128-byte lines.  Patterns are computed from the lane id (footprint <= 16 KB: always L1 hits).
+// addresses spread over 128-byte lines and inside a quad of lanes, and on lanes masked off.  Finding (profiles/r02): a quad whose
+// four addresses lie within two consecutive dwords is ONE access; any other quad is served lane by lane, ~1 clock per active lane.  Patterns are computed from the lane id (footprint <= 16 KB: always L1 hits).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -65,7 +66,9 @@ __global__ __launch_bounds__(256) void k_pat(const uint32_t* __restrict__ src, s
 			e[k] = 0;
 			const bool on = LMASK == 0 ? true : LMASK == 1 ? !(lane & 1) : LMASK == 2 ? !(lane & 3) : LMASK == 3 ? lane < 32 : LMASK == 4 ? !(lane & 4) : ((lane * 7 + k) % 3 == 0);
 			if (k < NLK && on) {
-				if (WIDE) e[k] = __builtin_amdgcn_raw_buffer_load_b32(lrs, addr(k, salt) & ~3u, 0, 0);
+				if (WIDE == 1) e[k] = __builtin_amdgcn_raw_buffer_load_b32(lrs, addr(k, salt) & ~3u, 0, 0);
+				else if (WIDE == 2) { const auto v = __builtin_amdgcn_raw_buffer_load_b64(lrs, addr(k, salt) & ~7u, 0, 0); e[k] = (uint32_t)v[0] ^ (uint32_t)v[1]; }
+				else if (WIDE == 3) { const auto v = __builtin_amdgcn_raw_buffer_load_b128(lrs, addr(k, salt) & ~15u, 0, 0); e[k] = (uint32_t)v[0] ^ (uint32_t)v[1] ^ (uint32_t)v[2] ^ (uint32_t)v[3]; }
 				else e[k] = (uint16_t)__builtin_amdgcn_raw_buffer_load_b16(lrs, addr(k, salt), 0, 0);
 			}
 		}
@@ -107,16 +110,41 @@ int main()
 #define RM(P, N, M, name) do { for (int w : {16}) { float ms = run<P, N, 0, M>(src, nitems, lut, sink, ncu, w); \
 		printf("%-58s N=%2d w=%2d  %6.1f ns/item/CU  %5.2f TB/s\n", name, N, w, ms * 1e6 / (nitems / (double)ncu), bytes / ms / 1e9); } fflush(stdout); } while (0)
 	RM(0, 0, 0, "no look-ups");
-	RM(2, 16, 0, "P2 quad: one address");
+	RM(0, 16, 0, "P0 all lanes one address");
+	RM(1, 16, 0, "P1 one line, 64 entries (u16 lane)");
+	RM(7, 16, 0, "P7 4 lines of 16 consecutive lanes");
+	RM(2, 16, 0, "P2 a line per quad, one address in the quad");
 	RM(14, 16, 0, "P14 quad: u16 {0,1,2,3}");
 	RM(16, 16, 0, "P16 quad: u16 {0,0,1,1}");
 	RM(17, 16, 0, "P17 quad: u16 {0,1,1,2}");
 	RM(18, 16, 0, "P18 quad: u16 {3,0,2,1}");
 	RM(19, 16, 0, "P19 quad: u16 {0,2,0,2}");
 	RM(20, 16, 0, "P20 quad: u16 {2,3,4,5}");
-	RM(21, 16, 0, "P21 quad: u16 {0,0,4,4}");
 	RM(22, 16, 0, "P22 quad: u16 {0,0,0,1}");
+	RM(21, 16, 0, "P21 quad: u16 {0,0,4,4}");
 	RM(23, 16, 0, "P23 quad: u16 {0,0,0,8}");
+	RM(8, 16, 0, "P8 quad inside 16 B (one u16 per dword)");
+	RM(9, 16, 0, "P9 quad inside 32 B");
+	RM(10, 16, 0, "P10 quad inside 64 B");
+	RM(11, 16, 0, "P11 quad over 128 B");
+	RM(12, 16, 0, "P12 quad: 2 addresses x 2 lanes, one line");
+	RM(13, 16, 0, "P13 quad: 2 addresses on 2 lines");
+	RM(3, 16, 0, "P3 a line per quad, 4 entries in the quad");
+	RM(4, 16, 0, "P4 two lines per quad");
+	RM(6, 16, 0, "P6 16 lines, each quad on 4 different lines");
 	RM(5, 16, 0, "P5 64 lines");
+	RM(5, 8, 0, "P5, 8 look-ups");
+	RM(5, 16, 1, "P5, even lanes only (2 of each quad)");
+	RM(5, 16, 2, "P5, one lane of each quad");
+	RM(5, 16, 3, "P5, lanes 0-31");
+	RM(5, 16, 4, "P5, even quads only");
+	RM(5, 16, 5, "P5, a pseudo-random third of the lanes");
+	RM(2, 16, 1, "P2, even lanes only");
+	R(5, 16, 1, "P5 as dword loads");
+	R(5, 16, 2, "P5 as dwordx2 loads");
+	R(5, 16, 3, "P5 as dwordx4 loads");
+	R(5, 4, 3, "P5 as dwordx4 loads, 4 per lane");
+	R(5, 4, 0, "P5 u16, 4 per lane");
+	R(2, 16, 3, "P2 as dwordx4 loads");
 	return 0;
 }
