@@ -6,4 +6,4 @@ timeout -k 10 400 python -m pytest tests/test_gpu_hotpath.py -x -q -m gpu -k "en
 echo "$v pytest rc=$? $(tail -1 gpurun_out/b3_${v}_pytest.log)"
 done
 unset AGMV_HIP_LIB
-timeout -k 10 500 python tools/probe_multi.py synth,noise3,flat BASE "$@" $EXTRA 2>&1 | grep -v amdgpu.ids | tee gpurun_out/b3_probe.txt
+timeout -k 10 500 python tools/probe_multi.py synth,noise3,flat,noise BASE "$@" $EXTRA 2>&1 | grep -v amdgpu.ids | tee gpurun_out/b3_probe.txt
