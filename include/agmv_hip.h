@@ -133,7 +133,22 @@ int agmv_hip_decode_frames_dev(agmv_hip_ctx* ctx, const uint8_t* d_bits, size_t 
                                uint32_t h, uint32_t first_frame_count, uint32_t* d_pix_out,
                                const uint32_t* d_prev_frame, const uint32_t* d_prev_iframe,
                                void* stream);
-/* After agmv_hip_decode_frames_dev: 1 when a pixel of that batch derives from d_prev_frame / d_prev_iframe (a block the
+/* How many frames of the last agmv_hip_parse_frames_dev call (of the last range, for agmv_hip_parse_decode_frames_dev)
+   the speculative parser could not prove and left to the robust kernels (0 for streams the encoder emits unless a
+   long run of FILL blocks carries a flag-valued index; damaged streams typically land here).  A statistic: the
+   outputs are the same either way.  Synchronises the stream; negative on error. */
+int agmv_hip_parse_fallback_frames(agmv_hip_ctx* ctx, void* stream);
+/* Both steps as ONE call, overlapped: the batch is cut into ranges of GOPs, the parser kernels (bound by instruction
+   issue, little memory traffic) run on a stream the context owns and the reconstruction of a range (bound by its pixel
+   stores) waits only for the parse of that range, so the parse of the next range shares the CUs with it.  Same inputs,
+   same outputs (d_offsets / d_nentered are written as by agmv_hip_parse_frames_dev), same pixels; everything is ordered
+   after the work already on `stream`, and `stream` is complete only when the whole call is. */
+int agmv_hip_parse_decode_frames_dev(agmv_hip_ctx* ctx, const uint8_t* d_bits, size_t bits_stride,
+                                     const uint32_t* d_bpos, uint32_t n_frames, uint32_t w, uint32_t h,
+                                     uint32_t first_frame_count, uint32_t* d_offsets, uint32_t* d_nentered,
+                                     uint32_t* d_pix_out, const uint32_t* d_prev_frame,
+                                     const uint32_t* d_prev_iframe, void* stream);
+/* After agmv_hip_decode_frames_dev / agmv_hip_parse_decode_frames_dev: 1 when a pixel of that batch derives from d_prev_frame / d_prev_iframe (a block the
    bitstream did not rewrite before it was read: stale tail after `escape`, COPY in the first GOP, a FILL / NORMAL block cut
    off by bpos -- reference src/agmv_decode.c:229-232, :268-271, :277-285, :310-314), 0 when the batch is a function of its
    own bitstreams alone, negative on error.  What a GOP-sharded decode needs to know before it trusts a range decoded from
@@ -159,7 +174,8 @@ int agmv_hip_histogram_dev(agmv_hip_ctx* ctx, const uint32_t* d_pix, size_t n_pi
 
 /* optional timing: when enabled the library records HIP events on the caller's stream around its three kernel
    groups; agmv_hip_last_kernel_ms(which) returns the last launch's duration in ms (0 = k_encode, 1 = the parser
-   kernels, 2 = k_decode + k_fixup), or a negative value if unavailable */
+   kernels, 2 = k_decode + k_fixup, 3 = the whole of agmv_hip_parse_decode_frames_dev), or a negative value if
+   unavailable */
 int   agmv_hip_enable_timing(agmv_hip_ctx* ctx, int on);
 float agmv_hip_last_kernel_ms(agmv_hip_ctx* ctx, int which);
 

@@ -101,6 +101,7 @@ constexpr int DEC_SR = DEC_STAGE / 4 / DEC_T;   // dwords of the window each lan
 #ifndef LUT_SPARSE
 #define LUT_SPARSE 1
 #endif
+constexpr int DEC_MAX_SLICES = 32;           // agmv_hip_parse_decode_frames_dev: GOP ranges whose parse overlaps the reconstruction of the range before
 constexpr uint32_t LUT_COLOURS = 1u << 24;
 constexpr uint32_t LUT_ENTRIES = LUT_SPARSE ? (1u << 28) : (1u << 24);   // index space of the table (see lut_index)
 
@@ -125,8 +126,12 @@ struct agmv_hip_ctx {
 	int n_cu;
 	uint32_t* d_parse_ws;           // parser workspace: cum | centry | summ
 	int timing;                     // record HIP events around the three hot kernels
-	hipEvent_t ev[6];               // encode, parse, decode: start/stop
+	hipEvent_t ev[8];               // encode, parse, decode, parse||decode pipeline: start/stop
 	size_t parse_ws_cap;            // in dwords
+	uint32_t* d_fp_ws;              // fast parser workspace: rec | vm | kb | fstate
+	size_t fp_ws_cap;               // in bytes
+	uint32_t* d_fp_fstate;          // frame states of the last parse (inside d_fp_ws) and how many
+	uint32_t fp_frames;
 	hipEvent_t ev_enc;              // end of the last encode launch (encodes of one context share status / control words)
 	hipStream_t enc_stream;         // ... and the stream it went to
 	int have_enc;
@@ -134,6 +139,9 @@ struct agmv_hip_ctx {
 	uint32_t* d_nn_pix;
 	uint16_t* d_nn_ent;
 	size_t nn_cap;
+	hipStream_t aux_stream;         // decode pipeline: the parser's stream (the reconstruction runs on the caller's)
+	hipEvent_t ev_fork;             // ... caller's stream -> parser's stream
+	hipEvent_t ev_slice[DEC_MAX_SLICES];   // ... slice parsed
 };
 
 extern "C" size_t agmv_hip_max_usize(uint32_t w, uint32_t h, int mode512)
@@ -968,7 +976,9 @@ struct ParseArgs {
 	uint32_t* offsets;
 	uint32_t* nentered;
 	uint32_t n_frames, nblk;
+	const uint32_t* fstate; // != NULL: only the frames the fast path gave up on (fstate[f] == FS_BAD) are parsed here
 };
+constexpr uint32_t FS_OK = 0, FS_TODO = 1, FS_BAD = 2;
 
 __global__ __launch_bounds__(64) void k_parse_prefix(ParseArgs A)
 {
@@ -976,7 +986,7 @@ __global__ __launch_bounds__(64) void k_parse_prefix(ParseArgs A)
 	uint32_t run = 0;
 	for (uint32_t f0 = 0; f0 < A.n_frames; f0 += 64) {
 		const uint32_t f = f0 + lane;
-		const uint32_t x = f < A.n_frames ? (A.bpos[f] + PC) / PC : 0u;     // ceil((bpos+1)/PC)
+		const uint32_t x = (f < A.n_frames && (!A.fstate || A.fstate[f] == FS_BAD)) ? (A.bpos[f] + PC) / PC : 0u;     // ceil((bpos+1)/PC)
 		const uint32_t incl = wave_incl_scan(x, lane);
 		if (f < A.n_frames) A.cum[f] = run + incl - x;
 		run += __shfl(incl, 63, 64);
@@ -1146,7 +1156,8 @@ __global__ __launch_bounds__(64) void k_parse_stitch(ParseArgs A)
 {
 	const uint32_t f = blockIdx.x;
 	const int lane = threadIdx.x;
-	const uint32_t c0 = A.cum[f], nch = A.cum[f + 1] - c0;     // nch >= 1
+	const uint32_t c0 = A.cum[f], nch = A.cum[f + 1] - c0;     // nch >= 1 for a frame that is parsed here
+	if (nch == 0) return;
 	const uint16_t* rows = A.summ + (size_t)c0 * 33 + (lane < 33 ? lane : 0);
 	uint32_t o = 0, kb = 0;
 	uint32_t nxt[PSB];
@@ -1245,6 +1256,288 @@ __global__ __launch_bounds__(64) void k_parse_emit(ParseArgs A)
 	}
 }
 
+// ----------------------------------------------------------------------------------------------
+// K2 (fast form): speculate, then PROVE.  The chain of block entries of a frame is unique: if a set of walks, one per
+// 64-byte piece of the stream, is such that every walk starts exactly where the walk of the piece before left off and
+// the first one starts at byte 0, their concatenation IS the reference's parse.  Chains that start at different bytes
+// merge within a few blocks (every block start the true chain passes is a flag byte the other chain will usually hit),
+// so a lane that walks its piece from "the first flag byte of the piece" almost always ends where the true chain ends:
+//   k_fp_walk   one wave per REGION of 59 pieces (+4 pieces of run-in before it, +1 behind it for the spill of the
+//               last block).  Every lane walks its piece from the first flag byte (types and lengths from bit masks
+//               built once per piece: flag bytes F, escape codes E; NORMAL lengths are computed for many lanes at once).
+//               Then each lane takes the exit of the lane before it as its true entry: if that entry slides onto a
+//               node of the walk it already has, the walk is trimmed; otherwise it walks from there until it hits a
+//               node of the old walk (merge) or leaves the piece.  Repeated until no lane's exit changes (1-2 rounds).
+//               Per piece: the bitmap V of block ENTRY positions (what offsets[] holds); per region: E (exit of the
+//               run-in = assumed entry of the region), X (exit of its last piece), N (entries).
+//   k_fp_scan   one wave per frame: region r is proven when E[r] == X[r-1] (region 0 starts at byte 0 by definition).
+//               A region that is not gets E := X[r-1] as a FORCED entry and is walked again (two repair rounds, exits
+//               that change cascade one region per round); a frame that is still unproven after those is left to the
+//               robust parser above.  Proven frames: exclusive sums of N -> first block number of every region, nentered.
+//   k_fp_expand bitmaps -> offsets[]: a lane per piece lists its set bits through LDS, rows are written coalesced.
+// Exit / entry codes: 0..33 = the next block is entered at that byte of the next piece; FX_SLIDE = no new entry, the
+// resync (src/agmv_decode.c:236-243) continues into the next piece; FX_END = the chain ended.
+// ----------------------------------------------------------------------------------------------
+constexpr int FC = 64;                  // bytes per piece (one lane)
+constexpr int FH = 4;                   // run-in pieces
+constexpr int FOWN = 64 - FH - 1;       // pieces a region owns (lane 63 holds the piece behind it)
+constexpr int FRB = FOWN * FC;          // bytes a region owns
+constexpr int FROW = FC / 4 + 1;        // LDS dwords per piece: its 16 + the first of the next piece (odd stride: no bank conflicts)
+constexpr uint32_t FX_SLIDE = 64u, FX_END = 65u, FX_UNSET = 66u, FX_MERGE = 128u;
+constexpr int FP_REPAIRS = 2;
+
+struct FpArgs {
+	const uint8_t* bits;
+	unsigned long long stride;
+	const uint32_t* bpos;
+	uint4* rec;                 // [n_frames][maxR]  x = E, y = X, z = N, w = walk again with E as the forced entry
+	unsigned long long* vm;     // [n_frames][maxR][FOWN] entry bitmaps
+	uint32_t* kb;               // [n_frames][maxR] first block number of the region
+	uint32_t* fstate;           // [n_frames] FS_*
+	uint32_t* offsets;
+	uint32_t* nentered;
+	uint32_t n_frames, nblk, maxR, pass;
+};
+
+__device__ __forceinline__ uint32_t ctz64(unsigned long long m) { return (uint32_t)__builtin_ctzll(m); }       // m != 0
+__device__ __forceinline__ uint32_t ctz64z(unsigned long long m) { return m ? (uint32_t)__builtin_ctzll(m) : 64u; }
+__device__ __forceinline__ unsigned long long above(uint32_t q) { return (~0ull << q) << 1; }     // bits > q (q <= 63)
+
+template <bool M512>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_fp_walk(FpArgs A)
+{
+	__shared__ uint32_t s_b[64 * FROW + 1];                    // (+1: lane 63's look at "the piece behind" stays inside)
+	const int lane = threadIdx.x;
+	const uint32_t f = blockIdx.y;
+	if (A.pass > 0 && A.fstate[f] != FS_TODO) return;
+	const uint32_t bpos = A.bpos[f];
+	const uint32_t nreg = min(bpos / FRB + 1u, A.maxR);        // positions 0 .. bpos can hold nodes
+	const uint8_t* fbits = A.bits + (size_t)f * A.stride;
+	const uint32_t cap = (uint32_t)A.stride;
+	for (uint32_t r = blockIdx.x; r < nreg; r += gridDim.x) {
+		uint4* rec = A.rec + (size_t)f * A.maxR + r;
+		uint32_t forced = FX_UNSET;
+		if (A.pass > 0) {
+			const uint4 v = *rec;
+			if (v.w == 0) continue;
+			forced = v.x;
+		}
+		if (r == 0) forced = 0;                                // block 0 is entered at byte 0
+		// ---- stage the 64 pieces (run-in, own, one behind); bytes before the frame or past the slab read as 0
+		const long sb = (long)r * FRB - FH * FC;
+		uint32_t raw[16];
+		const long pos0 = sb + 4 * lane;
+#pragma unroll
+		for (int k = 0; k < 16; k++) {
+			const long pos = pos0 + 256 * k;
+			raw[k] = (pos >= 0 && pos + 4 <= (long)cap) ? *(const uint32_t*)(fbits + pos) : 0u;
+		}
+		{
+			// dword i = 64 k + lane of the span is dword j = lane & 15 of piece 4 k + (lane >> 4): one base address + constants
+			uint32_t* row = s_b + (lane >> 4) * FROW + (lane & 15);
+#pragma unroll
+			for (int k = 0; k < 16; k++) row[k * 4 * FROW] = raw[k];
+		}
+		wave_lds_sync();
+		// ---- this lane's piece as bit masks, four bytes at a time: F flag bytes, C = 0x5E, L = 0x4E, E escape codes
+		const long cb = sb + (long)lane * FC;                  // first byte of the piece
+		unsigned long long F = 0, C = 0, L = 0, E = 0;
+		auto nib = [](uint32_t z) -> uint32_t { return ((z >> 7) | (z >> 14) | (z >> 21) | (z >> 28)) & 0xFu; };   // bit 7 of each byte -> 4 bits
+		auto zero7 = [](uint32_t v) -> uint32_t { return ~(((v & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | v) & 0x80808080u; };   // bit 7 of every byte that is 0 (exact)
+#pragma unroll
+		for (int j = 0; j < 16; j++) {
+			const uint32_t w = s_b[lane * FROW + j];
+			const uint32_t zl = zero7(w ^ 0x4E4E4E4Eu), zc = zero7(w ^ 0x5E5E5E5Eu), zn = zero7(w ^ 0x2F2F2F2Fu);
+			const unsigned long long nl = nib(zl), nc = nib(zc);
+			L |= nl << (4 * j); C |= nc << (4 * j);
+			F |= (nl | nc | (unsigned long long)nib(zn)) << (4 * j);
+			if (M512) E |= (unsigned long long)nib(((w & 0x7F7F7F7Fu) + 0x01010101u) & 0x80808080u) << (4 * j);   // (byte & 0x7f) == 127
+		}
+		{
+			const long nv = (long)bpos + 1 - cb;                   // bytes of the piece at positions <= bpos: only those are nodes
+			const unsigned long long ok = nv <= 0 ? 0ull : (nv < 64 ? (1ull << nv) - 1ull : ~0ull);
+			F &= ok;
+			// run skipping (below) only takes blocks that end at or before bpos: COPY at positions < bpos, two-byte FILL at positions < bpos - 1
+			C &= ok >> 1;
+			L &= ok >> 2;
+		}
+		const bool more = cb + FC <= (long)bpos;               // the stream goes on behind this piece
+		unsigned long long En = 0;                             // escape codes of the piece behind (a NORMAL body spills <= 33 bytes)
+		if (M512) {
+			const uint32_t lo = (uint32_t)__shfl_down((int)(uint32_t)E, 1, 64), hi = (uint32_t)__shfl_down((int)(uint32_t)(E >> 32), 1, 64);
+			En = lane < 63 ? ((unsigned long long)hi << 32 | lo) : 0ull;
+			L &= ~((E >> 1) | (En << 63));                     // FILL whose index byte is not an escape code: two bytes
+		}
+		const int first = forced != FX_UNSET ? FH : 0;          // first lane that walks (its entry: forced, or speculative)
+		const bool walker = lane >= first && lane < 63 && cb >= 0;
+		const uint32_t* mine = s_b + lane * FROW;
+		unsigned long long V = 0, Q = 0;                       // entries / nodes of the lane's walk
+		uint32_t xo = FX_UNSET, applied = FX_UNSET;
+		uint32_t want = (lane == first && forced != FX_UNSET) ? forced : FX_SLIDE;
+		const unsigned long long EVEN = 0x5555555555555555ull;
+		for (int round = 0; round < 66; round++) {
+			const bool need = walker && want != applied;
+			if (__ballot(need) == 0) break;
+			// ---- apply the entry `want`: trim the walk the lane has, or walk from the entry until it merges / leaves
+			bool go = false;
+			uint32_t q = 0, res = xo;
+			unsigned long long Vw = 0, Qw = 0;
+			if (need) {
+				applied = want;
+				if (want == FX_END) { V = 0; Q = 0; res = FX_END; }
+				else {
+					const uint32_t x = want == FX_SLIDE ? 0u : want;
+					Vw = want == FX_SLIDE ? 0ull : 1ull << x;
+					const unsigned long long m = F >> x;
+					if (m == 0) { V = Vw; Q = 0; res = more ? FX_SLIDE : FX_END; }
+					else {
+						q = x + ctz64(m);
+						if ((Q >> q) & 1ull) { V = Vw | (V & above(q)); Q &= ~0ull << q; }   // same chain from q on, same exit
+						else go = true;
+					}
+				}
+			}
+			// The walk, written without divergent branches (selects on every lane).  One step takes a whole RUN of blocks of
+			// the same kind when it can: consecutive COPY bytes, or two-byte FILLs back to back -- up to where the old walk
+			// has a node (the merge is found by the next step).
+			uint32_t wres = FX_UNSET;
+			for (;;) {
+				if (__ballot(go) == 0) break;
+				const unsigned long long Qq = Q >> q;
+				const bool merged = go && (Qq & 1ull);
+				wres = merged ? FX_MERGE + q : wres;
+				go = go && !merged;
+				const uint32_t d0 = mine[q >> 2], d1 = mine[(q >> 2) + 1];       // (dword 16 of a piece = pad, only read for its byte 64 = ...)
+				const uint32_t d1n = mine[FROW];                                   // ... the first dword of the piece behind
+				const uint32_t two = __builtin_amdgcn_alignbyte((q >> 2) == 15u ? d1n : d1, d0, q & 3u);
+				const uint32_t t = two & 0xFFu;
+				const bool isN = t == NORMAL_FLAG, isC = t == COPY_FLAG;
+				// run lengths (>= 1 for a COPY node; 0 for a FILL node that is not of the two-byte, inside-bpos kind)
+				const unsigned long long oldn = Qq & ~1ull;                       // old nodes behind q
+				const uint32_t rc = min(ctz64z(~(C >> q)), ctz64z(oldn));
+				const uint32_t rl = min(ctz64z(~(L >> q) & EVEN), ctz64z(oldn & EVEN)) >> 1;
+				uint32_t e;                                                        // end of the step
+				unsigned long long qm;                                             // the nodes it takes, as a mask from q
+				if (isC && rc > 0) { e = q + rc; qm = rc >= 64u ? ~0ull : (1ull << rc) - 1ull; }
+				else if (!isC && !isN && rl > 0) { e = q + 2u * rl; qm = (rl >= 32u ? ~0ull : (1ull << (2u * rl)) - 1ull) & EVEN; }
+				else { e = q + (isC ? 1u : 2u + ((M512 && ((two >> 8) & 0x7Fu) == 127u) ? 1u : 0u)); qm = 1ull; }
+				// NORMAL lengths for many lanes at once (16 dependent steps): when enough lanes wait, or nobody else moves
+				const unsigned long long pm = __ballot(go && isN), am = __ballot(go && !isN);
+				const bool doN = pm != 0 && (am == 0 || __popcll(pm) >= 16);
+				if (doN) {
+					uint32_t len = 16;
+					if (M512) {
+						const uint32_t q1 = q + 1u;
+						const uint32_t m = (uint32_t)((q1 < 64u ? E >> q1 : 0ull) | (En << (63u - q)));
+						uint32_t pos = 0;
+#pragma unroll
+						for (int i = 0; i < 16; i++) pos += 1u + ((m >> pos) & 1u);
+						len = pos;
+					}
+					if (isN) { e = q + 1u + len; qm = 1ull; }
+				}
+				const bool adv = go && (!isN || doN);
+				const bool over = cb + (long)e > (long)bpos;                       // entered, not counted: the chain ends
+				const bool cnt = adv && !over;
+				const unsigned long long qbits = qm << q;
+				Qw |= cnt ? qbits : 0ull;
+				// entries: one behind every node taken (at its end) -- those at byte 64 and beyond belong to the next piece
+				unsigned long long vb;
+				if (qm == 1ull) vb = e < 64u ? 1ull << e : 0ull;
+				else vb = isC ? qbits << 1 : qbits << 2;
+				Vw |= cnt ? vb : 0ull;
+				const unsigned long long m = e < 64u ? F >> e : 0ull;
+				const bool inside = cnt && e < 64u && m != 0;
+				const uint32_t stop = over ? FX_END : (e >= 64u ? e - 64u : (more ? FX_SLIDE : FX_END));
+				wres = (adv && !inside) ? stop : wres;
+				q = inside ? e + ctz64(m) : q;
+				go = go && (!adv || inside);
+			}
+			if (need && wres != FX_UNSET) {
+				if (wres >= FX_MERGE) {
+					const uint32_t mq = wres - FX_MERGE;
+					V = Vw | (V & above(mq)); Q = Qw | (Q & (~0ull << mq));
+				} else { V = Vw; Q = Qw; res = wres; }
+			}
+			if (need) xo = res;
+			// ---- next round: every lane's true entry is the exit of the lane before it
+			const uint32_t px = (uint32_t)__shfl_up((int)xo, 1, 64);
+			if (walker && lane > first) want = px;
+		}
+		// ---- results
+		const bool own = lane >= FH && lane < 63;
+		if (own) A.vm[((size_t)f * A.maxR + r) * FOWN + (lane - FH)] = walker ? V : 0ull;
+		const uint32_t n = wave_sum(own && walker ? (uint32_t)__popcll(V) : 0u);
+		const uint32_t ein = forced != FX_UNSET ? forced : (uint32_t)__builtin_amdgcn_readlane((int)xo, FH - 1);
+		const uint32_t xout = (uint32_t)__builtin_amdgcn_readlane((int)xo, 62);
+		if (lane == 0) *rec = make_uint4(ein, xout, n, 0u);
+		wave_lds_sync();
+	}
+}
+
+// one wave per frame: prove the regions (see above), force the entries of those that are not, or number the blocks
+__global__ __launch_bounds__(64) void k_fp_scan(FpArgs A)
+{
+	const uint32_t f = blockIdx.x;
+	const int lane = threadIdx.x;
+	if (A.pass > 0 && A.fstate[f] != FS_TODO) return;
+	const uint32_t nreg = min(A.bpos[f] / FRB + 1u, A.maxR);
+	uint4* rec = A.rec + (size_t)f * A.maxR;
+	uint32_t xprev = 0, nbad = 0;                              // exit of the region before (region 0: entry at byte 0)
+	for (uint32_t r0 = 0; r0 < nreg; r0 += 64) {
+		const uint32_t r = r0 + lane;
+		uint4 v = make_uint4(0, 0, 0, 0);
+		if (r < nreg) v = rec[r];
+		uint32_t xp = (uint32_t)__shfl_up((int)v.y, 1, 64);
+		if (lane == 0) xp = xprev;
+		const bool bad = r < nreg && v.x != xp;
+		if (bad && A.pass < (uint32_t)FP_REPAIRS) { v.x = xp; v.w = 1u; rec[r] = v; }
+		nbad += (uint32_t)__popcll(__ballot(bad));
+		xprev = (uint32_t)__builtin_amdgcn_readlane((int)v.y, 63 < nreg - r0 - 1 ? 63 : (int)(nreg - r0 - 1));
+	}
+	if (nbad) {
+		if (lane == 0) A.fstate[f] = A.pass < (uint32_t)FP_REPAIRS ? FS_TODO : FS_BAD;
+		return;
+	}
+	uint32_t run = 0;
+	for (uint32_t r0 = 0; r0 < nreg; r0 += 64) {
+		const uint32_t r = r0 + lane;
+		const uint32_t n = r < nreg ? rec[r].z : 0u;
+		const uint32_t incl = wave_incl_scan(n, lane);
+		if (r < nreg) A.kb[(size_t)f * A.maxR + r] = run + incl - n;
+		run += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+	}
+	if (lane == 0) { A.fstate[f] = FS_OK; A.nentered[f] = run < A.nblk ? run : A.nblk; }
+}
+
+// entry bitmaps -> offsets[]: lane = piece lists its set bits into the region's row in LDS, the row goes out coalesced
+__global__ __launch_bounds__(64) void k_fp_expand(FpArgs A)
+{
+	__shared__ uint16_t s_pos[FRB];
+	const int lane = threadIdx.x;
+	const uint32_t f = blockIdx.y;
+	if (A.fstate[f] != FS_OK) return;
+	const uint32_t nreg = min(A.bpos[f] / FRB + 1u, A.maxR);
+	uint32_t* off = A.offsets + (size_t)f * A.nblk;
+	for (uint32_t r = blockIdx.x; r < nreg; r += gridDim.x) {
+		const uint32_t kb = A.kb[(size_t)f * A.maxR + r];
+		if (kb >= A.nblk) break;                                // (uniform) blocks beyond the frame are never entered
+		unsigned long long V = lane < FOWN ? A.vm[((size_t)f * A.maxR + r) * FOWN + lane] : 0ull;
+		const uint32_t n = (uint32_t)__popcll(V);
+		const uint32_t incl = wave_incl_scan(n, lane);
+		const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+		uint32_t j = incl - n;
+		while (V) {
+			s_pos[j++] = (uint16_t)(lane * FC + ctz64(V));
+			V &= V - 1ull;
+		}
+		wave_lds_sync();
+		for (uint32_t i = lane; i < tot; i += 64)
+			if (kb + i < A.nblk) off[kb + i] = r * FRB + s_pos[i];
+		wave_lds_sync();
+	}
+}
+
 struct DecArgs {
 	const uint8_t* bits;
 	unsigned long long stride;
@@ -1257,6 +1550,7 @@ struct DecArgs {
 	const uint32_t* prev_iframe;
 	uint32_t* dirty;
 	uint32_t n_frames, w, h, bw, nblk, tpf, first_fc, phase, n_groups;
+	uint32_t grp0;          // first GOP of this launch (the grid covers GOPs grp0 .. grp0 + gridDim.x / tpf - 1)
 };
 
 // one 4x4 block of D2 (512 colours, src/agmv_decode.c:234-319) or D3 (256 colours, :335-396).
@@ -1444,7 +1738,7 @@ __global__ __launch_bounds__(DEC_T, DEC_WPE) void k_decode(DecArgs A)
 	const uint32_t npx = A.w * A.h;
 	for (int i = tid; i < 512; i += DEC_T) s_pal[i] = A.pal[i];
 
-	const uint32_t group = blockIdx.x / A.tpf, tile = blockIdx.x - group * A.tpf;
+	const uint32_t lgroup = blockIdx.x / A.tpf, tile = blockIdx.x - lgroup * A.tpf, group = lgroup + A.grp0;
 	const int f_lo = group == 0 ? 0 : (int)(group * 4 - A.phase);
 	int f_hi = (int)(group * 4 - A.phase) + 4;
 	if (f_hi > (int)A.n_frames) f_hi = (int)A.n_frames;
@@ -1823,10 +2117,13 @@ extern "C" void agmv_hip_destroy(agmv_hip_ctx* c)
 	if (!c) return;
 	(void)hipSetDevice(c->device);
 	(void)hipFree(c->d_lut); (void)hipFree(c->d_mtx); (void)hipFree(c->d_pal); (void)hipFree(c->d_ctrl);
-	(void)hipFree(c->d_status); (void)hipFree(c->d_dirty); (void)hipFree(c->d_parse_ws); (void)hipFree(c->d_ient_tmp);
+	(void)hipFree(c->d_status); (void)hipFree(c->d_dirty); (void)hipFree(c->d_parse_ws); (void)hipFree(c->d_fp_ws); (void)hipFree(c->d_ient_tmp);
 	(void)hipFree(c->d_nn_pal); (void)hipFree(c->d_nn_pix); (void)hipFree(c->d_nn_ent);
 	if (c->ev_enc) (void)hipEventDestroy(c->ev_enc);
-	for (int i = 0; i < 6; i++) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
+	for (int i = 0; i < 8; i++) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
+	if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+	for (int i = 0; i < DEC_MAX_SLICES; i++) if (c->ev_slice[i]) (void)hipEventDestroy(c->ev_slice[i]);
+	if (c->aux_stream) (void)hipStreamDestroy(c->aux_stream);
 	free(c);
 }
 
@@ -1839,17 +2136,17 @@ extern "C" int agmv_hip_enable_timing(agmv_hip_ctx* c, int on)
 {
 	if (!c) return -1;
 	CK(hipSetDevice(c->device));
-	if (on && !c->ev[0]) for (int i = 0; i < 6; i++) CK(hipEventCreate(&c->ev[i]));
+	if (on && !c->ev[0]) for (int i = 0; i < 8; i++) CK(hipEventCreate(&c->ev[i]));
 	c->timing = on ? 1 : 0;
 	return 0;
 }
 
 /* duration in ms of the last launch of kernel group `which` (0 = k_encode, 1 = the parser kernels,
-   2 = k_decode + k_fixup), measured with HIP events on the stream it ran on; synchronises on the stop event */
+   2 = k_decode + k_fixup, 3 = the whole of agmv_hip_parse_decode_frames_dev), measured with HIP events on the stream it ran on; synchronises on the stop event */
 extern "C" float agmv_hip_last_kernel_ms(agmv_hip_ctx* c, int which)
 {
 	float ms = -1.0f;
-	if (!c || !c->timing || which < 0 || which > 2) return -1.0f;
+	if (!c || !c->timing || which < 0 || which > 3) return -1.0f;
 	if (hipEventSynchronize(c->ev[2 * which + 1]) != hipSuccess) return -1.0f;
 	if (hipEventElapsedTime(&ms, c->ev[2 * which], c->ev[2 * which + 1]) != hipSuccess) return -1.0f;
 	return ms;
@@ -2096,6 +2393,100 @@ extern "C" int agmv_hip_nearest(agmv_hip_ctx* c, const uint32_t p0[256], const u
 	return 0;
 }
 
+static int check_slab(const uint8_t* d_bits, size_t stride)
+{
+	if ((stride & 3u) || stride < 4 || ((uintptr_t)d_bits & 3u)) { snprintf(g_err, sizeof(g_err), "agmv_hip: bitstream slab and stride must be 4-byte aligned"); return -1; }
+	return 0;
+}
+
+// the robust parser kernels over n_frames frames on stream s (workspace of the context: launches that share it must be
+// ordered); fstate != NULL: only the frames marked FS_BAD
+static int parse_launch_robust(agmv_hip_ctx* c, const uint8_t* d_bits, size_t stride, const uint32_t* d_bpos, uint32_t n_frames,
+                               uint32_t nblk, uint32_t* d_offsets, uint32_t* d_nentered, size_t ws_frames, const uint32_t* fstate, hipStream_t s)
+{
+	const size_t cpf = (stride + PC) / PC, maxchunks = cpf * ws_frames;
+	const size_t need = ws_frames + 1 + maxchunks + (maxchunks * 33 + 1) / 2 + 16;   // dwords: cum | centry | summ (u16)
+	if (need > c->parse_ws_cap) {
+		if (c->d_parse_ws) CK(hipFree(c->d_parse_ws));
+		c->d_parse_ws = nullptr; c->parse_ws_cap = 0;
+		CK(hipMalloc(&c->d_parse_ws, need * 4));
+		c->parse_ws_cap = need;
+	}
+	ParseArgs A;
+	memset(&A, 0, sizeof(A));
+	A.bits = d_bits; A.stride = stride; A.bpos = d_bpos; A.offsets = d_offsets; A.nentered = d_nentered;
+	A.cum = c->d_parse_ws; A.centry = A.cum + ws_frames + 1; A.summ = (uint16_t*)(A.centry + maxchunks);
+	A.n_frames = n_frames; A.nblk = nblk; A.fstate = fstate;
+	const dim3 gy(1, n_frames < 65535u ? n_frames : 65535u);
+	// one wave per workgroup, each striding over the chunks of one frame: ~512 waves per CU in the grid (measured on
+	// 1024 x 1080p: 8 / 16 / 32 / 64 / 128 / 256 per frame -> 2.85 / 2.30 / 1.96 / 1.87 / 1.83 / 1.84 ms)
+	uint32_t gx = (uint32_t)(((size_t)c->n_cu * 512 + n_frames - 1) / n_frames);
+	if (gx < 32) gx = 32;
+	if (gx > 256) gx = 256;
+	if (fstate) gx = 32;                                       // the exception path: most frames leave at once
+	if (getenv("AGMV_PARSE_GX")) gx = (uint32_t)atoi(getenv("AGMV_PARSE_GX"));   // tuning aid
+	if (gx > cpf) gx = (uint32_t)cpf;
+	if (gx < 1) gx = 1;
+	const dim3 grid(gx, gy.y);
+	hipLaunchKernelGGL(k_parse_prefix, dim3(1), dim3(64), 0, s, A);
+	CK(hipGetLastError());
+	if (c->mode512) hipLaunchKernelGGL(k_parse_chunks<true>, grid, dim3(64), 0, s, A);
+	else            hipLaunchKernelGGL(k_parse_chunks<false>, grid, dim3(64), 0, s, A);
+	CK(hipGetLastError());
+	hipLaunchKernelGGL(k_parse_stitch, dim3(n_frames), dim3(64), 0, s, A);
+	CK(hipGetLastError());
+	if (c->mode512) hipLaunchKernelGGL(k_parse_emit<true>, grid, dim3(64), 0, s, A);
+	else            hipLaunchKernelGGL(k_parse_emit<false>, grid, dim3(64), 0, s, A);
+	CK(hipGetLastError());
+	return 0;
+}
+
+// the parser: speculative walks proven per frame (k_fp_*), the robust kernels for the frames that could not be proven.
+// AGMV_HIP_PARSE=robust runs the robust kernels alone.
+static int parse_launch(agmv_hip_ctx* c, const uint8_t* d_bits, size_t stride, const uint32_t* d_bpos, uint32_t n_frames,
+                        uint32_t nblk, uint32_t* d_offsets, uint32_t* d_nentered, size_t ws_frames, hipStream_t s)
+{
+	const char* mode = getenv("AGMV_HIP_PARSE");
+	c->d_fp_fstate = nullptr; c->fp_frames = 0;
+	if (n_frames > 65535u || (mode && strcmp(mode, "robust") == 0))
+		return parse_launch_robust(c, d_bits, stride, d_bpos, n_frames, nblk, d_offsets, d_nentered, ws_frames, nullptr, s);
+	const size_t maxR = (stride + FRB - 1) / FRB + 1;
+	const size_t nreg = maxR * ws_frames;
+	const size_t b_rec = nreg * sizeof(uint4), b_vm = nreg * FOWN * 8, b_kb = nreg * 4, b_fs = ((ws_frames * 4 + 15) & ~(size_t)15);
+	const size_t need = b_rec + b_vm + b_kb + b_fs;
+	if (need > c->fp_ws_cap) {
+		if (c->d_fp_ws) CK(hipFree(c->d_fp_ws));
+		c->d_fp_ws = nullptr; c->fp_ws_cap = 0;
+		CK(hipMalloc(&c->d_fp_ws, need));
+		c->fp_ws_cap = need;
+	}
+	FpArgs A;
+	memset(&A, 0, sizeof(A));
+	A.bits = d_bits; A.stride = stride; A.bpos = d_bpos; A.offsets = d_offsets; A.nentered = d_nentered;
+	uint8_t* w = (uint8_t*)c->d_fp_ws;
+	A.rec = (uint4*)w; A.vm = (unsigned long long*)(w + b_rec); A.kb = (uint32_t*)(w + b_rec + b_vm); A.fstate = (uint32_t*)(w + b_rec + b_vm + b_kb);
+	A.n_frames = n_frames; A.nblk = nblk; A.maxR = (uint32_t)maxR;
+	uint32_t gx = (uint32_t)(((size_t)c->n_cu * 512 + n_frames - 1) / n_frames);
+	if (gx < 32) gx = 32;
+	if (gx > 256) gx = 256;
+	if (getenv("AGMV_PARSE_GX")) gx = (uint32_t)atoi(getenv("AGMV_PARSE_GX"));   // tuning aid
+	if (gx > maxR) gx = (uint32_t)maxR;
+	if (gx < 1) gx = 1;
+	const dim3 grid(gx, n_frames);
+	for (uint32_t pass = 0; pass <= (uint32_t)FP_REPAIRS; pass++) {
+		A.pass = pass;
+		if (c->mode512) hipLaunchKernelGGL(k_fp_walk<true>, grid, dim3(64), 0, s, A);
+		else            hipLaunchKernelGGL(k_fp_walk<false>, grid, dim3(64), 0, s, A);
+		CK(hipGetLastError());
+		hipLaunchKernelGGL(k_fp_scan, dim3(n_frames), dim3(64), 0, s, A);
+		CK(hipGetLastError());
+	}
+	hipLaunchKernelGGL(k_fp_expand, grid, dim3(64), 0, s, A);
+	CK(hipGetLastError());
+	c->d_fp_fstate = A.fstate; c->fp_frames = n_frames;
+	return parse_launch_robust(c, d_bits, stride, d_bpos, n_frames, nblk, d_offsets, d_nentered, ws_frames, A.fstate, s);
+}
+
 extern "C" int agmv_hip_parse_frames_dev(agmv_hip_ctx* c, const uint8_t* d_bits, size_t stride, const uint32_t* d_bpos,
                                          uint32_t n_frames, uint32_t w, uint32_t h, uint32_t* d_offsets, uint32_t* d_nentered,
                                          void* stream)
@@ -2112,59 +2503,36 @@ extern "C" int agmv_hip_parse_frames_dev(agmv_hip_ctx* c, const uint8_t* d_bits,
 		CK(hipGetLastError());
 		return 0;
 	}
-	if ((stride & 3u) || stride < 4 || ((uintptr_t)d_bits & 3u)) { snprintf(g_err, sizeof(g_err), "agmv_hip: bitstream slab and stride must be 4-byte aligned"); return -1; }
-	const size_t cpf = (stride + PC) / PC, maxchunks = cpf * n_frames;
-	const size_t need = (size_t)n_frames + 1 + maxchunks + (maxchunks * 33 + 1) / 2 + 16;   // dwords: cum | centry | summ (u16)
-	if (need > c->parse_ws_cap) {
-		if (c->d_parse_ws) CK(hipFree(c->d_parse_ws));
-		c->d_parse_ws = nullptr; c->parse_ws_cap = 0;
-		CK(hipMalloc(&c->d_parse_ws, need * 4));
-		c->parse_ws_cap = need;
-	}
-	ParseArgs A;
-	memset(&A, 0, sizeof(A));
-	A.bits = d_bits; A.stride = stride; A.bpos = d_bpos; A.offsets = d_offsets; A.nentered = d_nentered;
-	A.cum = c->d_parse_ws; A.centry = A.cum + n_frames + 1; A.summ = (uint16_t*)(A.centry + maxchunks);
-	A.n_frames = n_frames; A.nblk = nblk;
-	const dim3 gy(1, n_frames < 65535u ? n_frames : 65535u);
+	if (check_slab(d_bits, stride)) return -1;
 	ev_mark(c, 2, s);
-	// one wave per workgroup, each striding over the chunks of one frame: ~512 waves per CU in the grid (measured on
-	// 1024 x 1080p: 8 / 16 / 32 / 64 / 128 / 256 per frame -> 2.85 / 2.30 / 1.96 / 1.87 / 1.83 / 1.84 ms)
-	uint32_t gx = (uint32_t)(((size_t)c->n_cu * 512 + n_frames - 1) / n_frames);
-	if (gx < 32) gx = 32;
-	if (gx > 256) gx = 256;
-	if (getenv("AGMV_PARSE_GX")) gx = (uint32_t)atoi(getenv("AGMV_PARSE_GX"));   // tuning aid
-	if (gx > cpf) gx = (uint32_t)cpf;
-	if (gx < 1) gx = 1;
-	const dim3 grid(gx, gy.y);
-	hipLaunchKernelGGL(k_parse_prefix, dim3(1), dim3(64), 0, s, A);
-	CK(hipGetLastError());
-	if (c->mode512) hipLaunchKernelGGL(k_parse_chunks<true>, grid, dim3(64), 0, s, A);
-	else            hipLaunchKernelGGL(k_parse_chunks<false>, grid, dim3(64), 0, s, A);
-	CK(hipGetLastError());
-	hipLaunchKernelGGL(k_parse_stitch, dim3(n_frames), dim3(64), 0, s, A);
-	CK(hipGetLastError());
-	if (c->mode512) hipLaunchKernelGGL(k_parse_emit<true>, grid, dim3(64), 0, s, A);
-	else            hipLaunchKernelGGL(k_parse_emit<false>, grid, dim3(64), 0, s, A);
-	CK(hipGetLastError());
+	if (parse_launch(c, d_bits, stride, d_bpos, n_frames, nblk, d_offsets, d_nentered, n_frames, s)) return -1;
 	ev_mark(c, 3, s);
 	return 0;
 }
 
-extern "C" int agmv_hip_decode_frames_dev(agmv_hip_ctx* c, const uint8_t* d_bits, size_t stride, const uint32_t* d_bpos,
-                                          const uint32_t* d_offsets, const uint32_t* d_nentered, uint32_t n_frames,
-                                          uint32_t w, uint32_t h, uint32_t first_fc, uint32_t* d_out,
-                                          const uint32_t* d_prev, const uint32_t* d_prev_iframe, void* stream)
+extern "C" int agmv_hip_parse_fallback_frames(agmv_hip_ctx* c, void* stream)
 {
-	if (need_ctx(c, true)) return -1;
-	if (check_geometry(w, h)) return -1;
-	if (n_frames == 0) return 0;
+	if (need_ctx(c, false)) return -1;
+	if (!c->d_fp_fstate || c->fp_frames == 0) return 0;
+	CK(hipStreamSynchronize((hipStream_t)stream));
+	uint32_t* h = (uint32_t*)malloc((size_t)c->fp_frames * 4);
+	if (!h) { snprintf(g_err, sizeof(g_err), "agmv_hip: out of host memory"); return -1; }
+	if (hipMemcpy(h, c->d_fp_fstate, (size_t)c->fp_frames * 4, hipMemcpyDeviceToHost) != hipSuccess) { free(h); snprintf(g_err, sizeof(g_err), "agmv_hip: D2H failed"); return -1; }
+	int n = 0;
+	for (uint32_t i = 0; i < c->fp_frames; i++) n += h[i] != FS_OK;
+	free(h);
+	return n;
+}
+
+// arguments of k_decode / k_fixup for a batch; grows and clears the context's bitmap of positions to repair
+static int decode_prepare(agmv_hip_ctx* c, DecArgs& A, const uint8_t* d_bits, size_t stride, const uint32_t* d_bpos,
+                          const uint32_t* d_offsets, const uint32_t* d_nentered, uint32_t n_frames, uint32_t w, uint32_t h,
+                          uint32_t first_fc, uint32_t* d_out, const uint32_t* d_prev, const uint32_t* d_prev_iframe, hipStream_t s)
+{
 	if (((uintptr_t)d_out & 15u) || ((uintptr_t)d_prev & 15u) || ((uintptr_t)d_prev_iframe & 15u)) {
 		snprintf(g_err, sizeof(g_err), "agmv_hip: pixel buffers must be 16-byte aligned"); return -1;
 	}
-	if ((stride & 3u) || stride < 4 || ((uintptr_t)d_bits & 3u)) { snprintf(g_err, sizeof(g_err), "agmv_hip: bitstream slab and stride must be 4-byte aligned"); return -1; }
-	hipStream_t s = (hipStream_t)stream;
-	DecArgs A;
+	if (check_slab(d_bits, stride)) return -1;
 	memset(&A, 0, sizeof(A));
 	A.bits = d_bits; A.stride = stride; A.bpos = d_bpos; A.offsets = d_offsets; A.nentered = d_nentered;
 	A.out = d_out; A.pal = c->d_pal; A.prev = d_prev; A.prev_iframe = d_prev_iframe;
@@ -2181,18 +2549,94 @@ extern "C" int agmv_hip_decode_frames_dev(agmv_hip_ctx* c, const uint8_t* d_bits
 	}
 	A.dirty = c->d_dirty;
 	CK(hipMemsetAsync(c->d_dirty, 0, nwords * 4, s));
-	ev_mark(c, 4, s);
-	if (c->mode512) {
-		hipLaunchKernelGGL(k_decode<true>, dim3(A.n_groups * A.tpf), dim3(DEC_T), 0, s, A);
-		CK(hipGetLastError());
-		hipLaunchKernelGGL(k_fixup<true>, dim3((A.nblk + 63) / 64), dim3(64), 0, s, A);
-	} else {
-		hipLaunchKernelGGL(k_decode<false>, dim3(A.n_groups * A.tpf), dim3(DEC_T), 0, s, A);
-		CK(hipGetLastError());
-		hipLaunchKernelGGL(k_fixup<false>, dim3((A.nblk + 63) / 64), dim3(64), 0, s, A);
-	}
+	return 0;
+}
+
+static int decode_launch(agmv_hip_ctx* c, DecArgs A, uint32_t g0, uint32_t g1, hipStream_t s)   // GOPs [g0, g1) of the batch
+{
+	A.grp0 = g0;
+	if (c->mode512) hipLaunchKernelGGL(k_decode<true>, dim3((g1 - g0) * A.tpf), dim3(DEC_T), 0, s, A);
+	else            hipLaunchKernelGGL(k_decode<false>, dim3((g1 - g0) * A.tpf), dim3(DEC_T), 0, s, A);
 	CK(hipGetLastError());
+	return 0;
+}
+
+static int fixup_launch(agmv_hip_ctx* c, const DecArgs& A, hipStream_t s)
+{
+	if (c->mode512) hipLaunchKernelGGL(k_fixup<true>, dim3((A.nblk + 63) / 64), dim3(64), 0, s, A);
+	else            hipLaunchKernelGGL(k_fixup<false>, dim3((A.nblk + 63) / 64), dim3(64), 0, s, A);
+	CK(hipGetLastError());
+	return 0;
+}
+
+extern "C" int agmv_hip_decode_frames_dev(agmv_hip_ctx* c, const uint8_t* d_bits, size_t stride, const uint32_t* d_bpos,
+                                          const uint32_t* d_offsets, const uint32_t* d_nentered, uint32_t n_frames,
+                                          uint32_t w, uint32_t h, uint32_t first_fc, uint32_t* d_out,
+                                          const uint32_t* d_prev, const uint32_t* d_prev_iframe, void* stream)
+{
+	if (need_ctx(c, true)) return -1;
+	if (check_geometry(w, h)) return -1;
+	if (n_frames == 0) return 0;
+	hipStream_t s = (hipStream_t)stream;
+	DecArgs A;
+	if (decode_prepare(c, A, d_bits, stride, d_bpos, d_offsets, d_nentered, n_frames, w, h, first_fc, d_out, d_prev, d_prev_iframe, s)) return -1;
+	ev_mark(c, 4, s);
+	if (decode_launch(c, A, 0, A.n_groups, s)) return -1;
+	if (fixup_launch(c, A, s)) return -1;
 	ev_mark(c, 5, s);
+	return 0;
+}
+
+// Parse + reconstruct as ONE call.  The parser kernels are bound by instruction issue and move little data, k_decode is
+// bound by its pixel stores and issues little: the batch is cut into ranges of GOPs, the parser runs on a stream of the
+// context's own, and the reconstruction of range k (caller's stream) waits only for the parse of range k, so the parse
+// of range k+1 shares the CUs with it.  k_fixup needs every frame's offsets and runs last.
+extern "C" int agmv_hip_parse_decode_frames_dev(agmv_hip_ctx* c, const uint8_t* d_bits, size_t stride, const uint32_t* d_bpos,
+                                                uint32_t n_frames, uint32_t w, uint32_t h, uint32_t first_fc,
+                                                uint32_t* d_offsets, uint32_t* d_nentered, uint32_t* d_out,
+                                                const uint32_t* d_prev, const uint32_t* d_prev_iframe, void* stream)
+{
+	if (need_ctx(c, true)) return -1;
+	if (check_geometry(w, h)) return -1;
+	if (n_frames == 0) return 0;
+	hipStream_t s = (hipStream_t)stream;
+	DecArgs A;
+	if (decode_prepare(c, A, d_bits, stride, d_bpos, d_offsets, d_nentered, n_frames, w, h, first_fc, d_out, d_prev, d_prev_iframe, s)) return -1;
+	// ranges: at least DEC_SLICE_MIN GOPs each (a launch must still fill the chip), at most DEC_MAX_SLICES of them
+	uint32_t nsl = 8;
+	if (getenv("AGMV_DEC_SLICES")) nsl = (uint32_t)atoi(getenv("AGMV_DEC_SLICES"));   // tuning aid
+	const uint32_t min_groups = (uint32_t)(((size_t)c->n_cu * 16 + A.tpf - 1) / A.tpf);   // ~16 workgroups per CU and launch
+	if (nsl > A.n_groups / (min_groups ? min_groups : 1u)) nsl = A.n_groups / (min_groups ? min_groups : 1u);
+	if (nsl > (uint32_t)DEC_MAX_SLICES) nsl = DEC_MAX_SLICES;
+	if (nsl < 1) nsl = 1;
+	const uint32_t gps = (A.n_groups + nsl - 1) / nsl;         // GOPs per range
+	auto first_frame = [&](uint32_t g) -> uint32_t { const long f = (long)g * 4 - (long)A.phase; return f < 0 ? 0u : ((uint32_t)f > n_frames ? n_frames : (uint32_t)f); };
+	const size_t ws_frames = (size_t)gps * 4;
+	ev_mark(c, 6, s);
+	if (nsl == 1) {
+		if (parse_launch(c, d_bits, stride, d_bpos, n_frames, A.nblk, d_offsets, d_nentered, n_frames, s)) return -1;
+		if (decode_launch(c, A, 0, A.n_groups, s)) return -1;
+	} else {
+		if (!c->aux_stream) {
+			CK(hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking));
+			CK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+			for (int i = 0; i < DEC_MAX_SLICES; i++) CK(hipEventCreateWithFlags(&c->ev_slice[i], hipEventDisableTiming));
+		}
+		CK(hipEventRecord(c->ev_fork, s));                     // the bitstreams are complete on the caller's stream
+		CK(hipStreamWaitEvent(c->aux_stream, c->ev_fork, 0));
+		uint32_t k = 0;
+		for (uint32_t g0 = 0; g0 < A.n_groups; g0 += gps, k++) {
+			const uint32_t g1 = g0 + gps < A.n_groups ? g0 + gps : A.n_groups;
+			const uint32_t f0 = first_frame(g0), f1 = first_frame(g1);
+			if (parse_launch(c, d_bits + (size_t)f0 * stride, stride, d_bpos + f0, f1 - f0, A.nblk, d_offsets + (size_t)f0 * A.nblk,
+			                 d_nentered + f0, ws_frames, c->aux_stream)) return -1;
+			CK(hipEventRecord(c->ev_slice[k], c->aux_stream));
+			CK(hipStreamWaitEvent(s, c->ev_slice[k], 0));
+			if (decode_launch(c, A, g0, g1, s)) return -1;
+		}
+	}
+	if (fixup_launch(c, A, s)) return -1;
+	ev_mark(c, 7, s);
 	return 0;
 }
 
