@@ -1264,17 +1264,18 @@ __global__ __launch_bounds__(64) void k_parse_emit(ParseArgs A)
 // so a lane that walks its piece from "the first flag byte of the piece" almost always ends where the true chain ends:
 //   k_fp_walk   one wave per REGION of 59 pieces (+4 pieces of run-in before it, +1 behind it for the spill of the
 //               last block).  Every lane walks its piece from the first flag byte (types and lengths from bit masks
-//               built once per piece: flag bytes F, escape codes E; NORMAL lengths are computed for many lanes at once).
-//               Then each lane takes the exit of the lane before it as its true entry: if that entry slides onto a
-//               node of the walk it already has, the walk is trimmed; otherwise it walks from there until it hits a
-//               node of the old walk (merge) or leaves the piece.  Repeated until no lane's exit changes (1-2 rounds).
+//               built once per piece: flag bytes F, COPY bytes C, two-byte FILLs L, escape codes E; a step takes a whole
+//               run of COPYs or of two-byte FILLs; NORMAL lengths are computed for many lanes at once).  Then each lane
+//               takes the exit of the lane before it as its true entry: if that entry slides onto a node of the walk it
+//               already has, the walk is trimmed; otherwise it walks from there until it hits a node of the old walk
+//               (merge) or leaves the piece.  Repeated until no lane's exit changes (1-2 rounds).
 //               Per piece: the bitmap V of block ENTRY positions (what offsets[] holds); per region: E (exit of the
 //               run-in = assumed entry of the region), X (exit of its last piece), N (entries).
-//   k_fp_scan   one wave per frame: region r is proven when E[r] == X[r-1] (region 0 starts at byte 0 by definition).
-//               A region that is not gets E := X[r-1] as a FORCED entry and is walked again (two repair rounds, exits
-//               that change cascade one region per round); a frame that is still unproven after those is left to the
-//               robust parser above.  Proven frames: exclusive sums of N -> first block number of every region, nentered.
-//   k_fp_expand bitmaps -> offsets[]: a lane per piece lists its set bits through LDS, rows are written coalesced.
+//   k_fp_finish one wave per frame: region r is proven when E[r] == X[r-1] (region 0 starts at byte 0 by definition).
+//               Regions that are not are walked again, in order, with X[r-1] as a FORCED entry (an exit that changes
+//               carries on into the next region); a frame that needs more than FP_REPAIRS of those is left to the robust
+//               parser above.  Proven frames: exclusive sums of N -> first block number of every region, nentered.
+//   k_fp_expand bitmaps -> offsets[]: per piece, the lanes whose bit is set write their position at the rank of the bit.
 // Exit / entry codes: 0..33 = the next block is entered at that byte of the next piece; FX_SLIDE = no new entry, the
 // resync (src/agmv_decode.c:236-243) continues into the next piece; FX_END = the chain ended.
 // ----------------------------------------------------------------------------------------------
@@ -1282,227 +1283,235 @@ constexpr int FC = 64;                  // bytes per piece (one lane)
 constexpr int FH = 4;                   // run-in pieces
 constexpr int FOWN = 64 - FH - 1;       // pieces a region owns (lane 63 holds the piece behind it)
 constexpr int FRB = FOWN * FC;          // bytes a region owns
-constexpr int FROW = FC / 4 + 1;        // LDS dwords per piece: its 16 + the first of the next piece (odd stride: no bank conflicts)
+constexpr int FROW = FC / 4 + 1;        // LDS dwords per piece (odd stride: no bank conflicts between the lanes' pieces)
 constexpr uint32_t FX_SLIDE = 64u, FX_END = 65u, FX_UNSET = 66u, FX_MERGE = 128u;
-constexpr int FP_REPAIRS = 2;
+constexpr int FP_REPAIRS = 24;          // regions of one frame walked again (serially, by the frame's wave) before the frame is given up
+constexpr int FP_LDS = 64 * FROW + 1;   // (+1: lane 63's look at "the piece behind" stays inside)
 
 struct FpArgs {
 	const uint8_t* bits;
 	unsigned long long stride;
 	const uint32_t* bpos;
-	uint4* rec;                 // [n_frames][maxR]  x = E, y = X, z = N, w = walk again with E as the forced entry
+	uint4* rec;                 // [n_frames][maxR]  x = E, y = X, z = N
 	unsigned long long* vm;     // [n_frames][maxR][FOWN] entry bitmaps
 	uint32_t* kb;               // [n_frames][maxR] first block number of the region
-	uint32_t* fstate;           // [n_frames] FS_*
+	uint32_t* fstate;           // [n_frames] FS_OK / FS_BAD
 	uint32_t* offsets;
 	uint32_t* nentered;
-	uint32_t n_frames, nblk, maxR, pass;
+	uint32_t n_frames, nblk, maxR;
 };
 
 __device__ __forceinline__ uint32_t ctz64(unsigned long long m) { return (uint32_t)__builtin_ctzll(m); }       // m != 0
-__device__ __forceinline__ uint32_t ctz64z(unsigned long long m) { return m ? (uint32_t)__builtin_ctzll(m) : 64u; }
 __device__ __forceinline__ unsigned long long above(uint32_t q) { return (~0ull << q) << 1; }     // bits > q (q <= 63)
+
+// one region (see above) by one wave; forced = FX_UNSET: the entry of the region is what the run-in pieces give
+template <bool M512>
+__device__ __forceinline__ void fp_walk_region(const FpArgs& A, uint32_t* s_b, uint32_t f, uint32_t r, uint32_t forced, uint32_t bpos, int lane)
+{
+	const uint8_t* fbits = A.bits + (size_t)f * A.stride;
+	const uint32_t cap = (uint32_t)A.stride;
+	// ---- stage the 64 pieces (run-in, own, one behind); bytes before the frame or past the slab read as 0
+	const long sb = (long)r * FRB - FH * FC;
+	uint32_t raw[16];
+	const long pos0 = sb + 4 * lane;
+#pragma unroll
+	for (int k = 0; k < 16; k++) {
+		const long pos = pos0 + 256 * k;
+		raw[k] = (pos >= 0 && pos + 4 <= (long)cap) ? *(const uint32_t*)(fbits + pos) : 0u;
+	}
+	{
+		// dword i = 64 k + lane of the span is dword j = lane & 15 of piece 4 k + (lane >> 4): one base address + constants
+		uint32_t* row = s_b + (lane >> 4) * FROW + (lane & 15);
+#pragma unroll
+		for (int k = 0; k < 16; k++) row[k * 4 * FROW] = raw[k];
+	}
+	wave_lds_sync();
+	// ---- this lane's piece as bit masks, four bytes at a time: F flag bytes, C = 0x5E, L = 0x4E, E escape codes
+	const long cb = sb + (long)lane * FC;                      // first byte of the piece
+	unsigned long long F, C, L, E = 0;
+	{
+		auto nib = [](uint32_t z) -> uint32_t { return ((z >> 7) | (z >> 14) | (z >> 21) | (z >> 28)) & 0xFu; };   // bit 7 of each byte -> 4 bits
+		auto zero7 = [](uint32_t v) -> uint32_t { return ~(((v & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | v) & 0x80808080u; };   // bit 7 of every byte that is 0 (exact)
+		uint32_t f2[2] = {0, 0}, c2[2] = {0, 0}, l2[2] = {0, 0}, e2[2] = {0, 0};
+#pragma unroll
+		for (int j = 0; j < 16; j++) {
+			const uint32_t w = s_b[lane * FROW + j];
+			const uint32_t nl = nib(zero7(w ^ 0x4E4E4E4Eu)), nc = nib(zero7(w ^ 0x5E5E5E5Eu)), nn = nib(zero7(w ^ 0x2F2F2F2Fu));
+			l2[j >> 3] |= nl << (4 * (j & 7)); c2[j >> 3] |= nc << (4 * (j & 7));
+			f2[j >> 3] |= (nl | nc | nn) << (4 * (j & 7));
+			if (M512) e2[j >> 3] |= nib(((w & 0x7F7F7F7Fu) + 0x01010101u) & 0x80808080u) << (4 * (j & 7));   // (byte & 0x7f) == 127
+		}
+		F = (unsigned long long)f2[1] << 32 | f2[0]; C = (unsigned long long)c2[1] << 32 | c2[0];
+		L = (unsigned long long)l2[1] << 32 | l2[0]; E = (unsigned long long)e2[1] << 32 | e2[0];
+	}
+	const long lim_l = (long)bpos - cb;                        // a block of this piece counts when it ends at or before this offset
+	const int lim = lim_l > 1000 ? 1000 : (lim_l < -1000 ? -1000 : (int)lim_l);
+	{
+		const long nv = lim_l + 1;                             // bytes of the piece at positions <= bpos: only those are nodes
+		const unsigned long long ok = nv <= 0 ? 0ull : (nv < 64 ? (1ull << nv) - 1ull : ~0ull);
+		F &= ok;
+		// run skipping (below) only takes blocks that end at or before bpos: COPY at positions < bpos, two-byte FILL at positions < bpos - 1
+		C &= ok >> 1;
+		L &= ok >> 2;
+	}
+	const bool more = lim >= FC;                               // the stream goes on behind this piece
+	unsigned long long En = 0;                                 // escape codes of the piece behind (a NORMAL body spills <= 33 bytes)
+	if (M512) {
+		const uint32_t lo = (uint32_t)__shfl_down((int)(uint32_t)E, 1, 64), hi = (uint32_t)__shfl_down((int)(uint32_t)(E >> 32), 1, 64);
+		En = lane < 63 ? ((unsigned long long)hi << 32 | lo) : 0ull;
+		L &= ~((E >> 1) | (En << 63));                         // FILL whose index byte is not an escape code: two bytes
+	}
+	const int first = forced != FX_UNSET ? FH : 0;              // first lane that walks (its entry: forced, or speculative)
+	const bool walker = lane >= first && lane < 63 && cb >= 0;
+	const uint32_t* mine = s_b + lane * FROW;
+	const uint32_t behind = mine[FROW];                        // first dword of the piece behind
+	unsigned long long V = 0, Q = 0;                           // entries / nodes of the lane's walk
+	uint32_t xo = FX_UNSET, applied = FX_UNSET;
+	uint32_t want = (lane == first && forced != FX_UNSET) ? forced : FX_SLIDE;
+	for (int round = 0; round < 66; round++) {
+		const bool need = walker && want != applied;
+		if (__ballot(need) == 0) break;
+		// ---- apply the entry `want`: trim the walk the lane has, or walk from the entry until it merges / leaves
+		bool go = false;
+		uint32_t q = 0, res = xo;
+		unsigned long long Vw = 0, Qw = 0;
+		if (need) {
+			applied = want;
+			if (want == FX_END) { V = 0; Q = 0; res = FX_END; }
+			else {
+				const uint32_t x = want == FX_SLIDE ? 0u : want;
+				Vw = want == FX_SLIDE ? 0ull : 1ull << x;
+				const unsigned long long m = F >> x;
+				if (m == 0) { V = Vw; Q = 0; res = more ? FX_SLIDE : FX_END; }
+				else {
+					q = x + ctz64(m);
+					if ((Q >> q) & 1ull) { V = Vw | (V & above(q)); Q &= ~0ull << q; }   // same chain from q on, same exit
+					else go = true;
+				}
+			}
+		}
+		// The walk, written without divergent branches (selects on every lane).  One step takes a whole RUN of blocks of
+		// the same kind when it can: consecutive COPY bytes, or two-byte FILLs back to back -- at most 31 bytes of them, and
+		// only up to where the old walk has a node (the merge is found by the next step).
+		uint32_t wres = FX_UNSET;
+		for (;;) {
+			if (__ballot(go) == 0) break;
+			const uint32_t q32 = (uint32_t)(Q >> q), c32 = (uint32_t)(C >> q), l32 = (uint32_t)(L >> q);   // 32-byte windows from q
+			const bool merged = go && (q32 & 1u);
+			wres = merged ? FX_MERGE + q : wres;
+			go = go && !merged;
+			const uint32_t d0 = mine[q >> 2], d1 = mine[(q >> 2) + 1];
+			const uint32_t two = __builtin_amdgcn_alignbyte((q >> 2) == 15u ? behind : d1, d0, q & 3u);
+			const uint32_t t = two & 0xFFu;
+			const bool isN = t == NORMAL_FLAG, isC = t == COPY_FLAG;
+			// blocks the step takes: a run of COPYs / of two-byte FILLs (bit 31 / bit 30 stop the count), else one
+			const uint32_t oldn = q32 & ~1u;                       // old nodes behind q
+			const uint32_t rc = (uint32_t)__builtin_ctz(~c32 | oldn | 0x80000000u);
+			const uint32_t rl = (uint32_t)__builtin_ctz(((~l32 | oldn) & 0x55555555u) | 0x40000000u) >> 1;
+			uint32_t len1 = isC ? 1u : 2u + ((M512 && ((two >> 8) & 0x7Fu) == 127u) ? 1u : 0u);   // length of the block at q
+			uint32_t nrun = 1, qm = 1;                             // blocks taken; their nodes as a mask from q
+			if (isC && rc > 1u) { nrun = rc; qm = (1u << rc) - 1u; }
+			if (!isC && !isN && rl > 1u) { nrun = rl; qm = ((1u << (2u * rl)) - 1u) & 0x55555555u; }
+			// NORMAL lengths for many lanes at once (16 dependent steps): when enough lanes wait, or nobody else moves
+			const unsigned long long pm = __ballot(go && isN), am = __ballot(go && !isN);
+			const bool doN = pm != 0 && (am == 0 || __popcll(pm) >= 16);
+			if (doN) {
+				uint32_t len = 16;
+				if (M512) {
+					const uint32_t q1 = q + 1u;
+					const uint32_t m = (uint32_t)((q1 < 64u ? E >> q1 : 0ull) | (En << (63u - q)));
+					uint32_t pos = 0;
+#pragma unroll
+					for (int i = 0; i < 16; i++) pos += 1u + ((m >> pos) & 1u);
+					len = pos;
+				}
+				if (isN) len1 = 1u + len;
+			}
+			const uint32_t e = q + nrun * len1;                    // (runs: every block has the length of the first)
+			const bool adv = go && (!isN || doN);
+			const bool over = (int)e > lim;                        // entered, not counted: the chain ends
+			const bool cnt = adv && !over;
+			const unsigned long long qbits = (unsigned long long)qm << q;
+			Qw |= cnt ? qbits : 0ull;
+			Vw |= cnt ? qbits << len1 : 0ull;                      // an entry behind every node taken; those at byte 64 and beyond belong to the next piece
+			const unsigned long long m = F >> (e & 63u);
+			const bool inside = cnt && e < 64u && m != 0;
+			const uint32_t stop = over ? FX_END : (e >= 64u ? e - 64u : (more ? FX_SLIDE : FX_END));
+			wres = (adv && !inside) ? stop : wres;
+			q = inside ? e + ctz64(m) : q;
+			go = go && (!adv || inside);
+		}
+		if (need && wres != FX_UNSET) {
+			if (wres >= FX_MERGE) {
+				const uint32_t mq = wres - FX_MERGE;
+				V = Vw | (V & above(mq)); Q = Qw | (Q & (~0ull << mq));
+			} else { V = Vw; Q = Qw; res = wres; }
+		}
+		if (need) xo = res;
+		// ---- next round: every lane's true entry is the exit of the lane before it
+		const uint32_t px = (uint32_t)__shfl_up((int)xo, 1, 64);
+		if (walker && lane > first) want = px;
+	}
+	// ---- results
+	const bool own = lane >= FH && lane < 63;
+	if (own) A.vm[((size_t)f * A.maxR + r) * FOWN + (lane - FH)] = walker ? V : 0ull;
+	const uint32_t n = wave_sum(own && walker ? (uint32_t)__popcll(V) : 0u);
+	const uint32_t ein = forced != FX_UNSET ? forced : (uint32_t)__builtin_amdgcn_readlane((int)xo, FH - 1);
+	const uint32_t xout = (uint32_t)__builtin_amdgcn_readlane((int)xo, 62);
+	if (lane == 0) A.rec[(size_t)f * A.maxR + r] = make_uint4(ein, xout, n, 0u);
+	wave_lds_sync();
+}
 
 template <bool M512>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_fp_walk(FpArgs A)
 {
-	__shared__ uint32_t s_b[64 * FROW + 1];                    // (+1: lane 63's look at "the piece behind" stays inside)
+	__shared__ uint32_t s_b[FP_LDS];
 	const int lane = threadIdx.x;
 	const uint32_t f = blockIdx.y;
-	if (A.pass > 0 && A.fstate[f] != FS_TODO) return;
 	const uint32_t bpos = A.bpos[f];
 	const uint32_t nreg = min(bpos / FRB + 1u, A.maxR);        // positions 0 .. bpos can hold nodes
-	const uint8_t* fbits = A.bits + (size_t)f * A.stride;
-	const uint32_t cap = (uint32_t)A.stride;
-	for (uint32_t r = blockIdx.x; r < nreg; r += gridDim.x) {
-		uint4* rec = A.rec + (size_t)f * A.maxR + r;
-		uint32_t forced = FX_UNSET;
-		if (A.pass > 0) {
-			const uint4 v = *rec;
-			if (v.w == 0) continue;
-			forced = v.x;
-		}
-		if (r == 0) forced = 0;                                // block 0 is entered at byte 0
-		// ---- stage the 64 pieces (run-in, own, one behind); bytes before the frame or past the slab read as 0
-		const long sb = (long)r * FRB - FH * FC;
-		uint32_t raw[16];
-		const long pos0 = sb + 4 * lane;
-#pragma unroll
-		for (int k = 0; k < 16; k++) {
-			const long pos = pos0 + 256 * k;
-			raw[k] = (pos >= 0 && pos + 4 <= (long)cap) ? *(const uint32_t*)(fbits + pos) : 0u;
-		}
-		{
-			// dword i = 64 k + lane of the span is dword j = lane & 15 of piece 4 k + (lane >> 4): one base address + constants
-			uint32_t* row = s_b + (lane >> 4) * FROW + (lane & 15);
-#pragma unroll
-			for (int k = 0; k < 16; k++) row[k * 4 * FROW] = raw[k];
-		}
-		wave_lds_sync();
-		// ---- this lane's piece as bit masks, four bytes at a time: F flag bytes, C = 0x5E, L = 0x4E, E escape codes
-		const long cb = sb + (long)lane * FC;                  // first byte of the piece
-		unsigned long long F = 0, C = 0, L = 0, E = 0;
-		auto nib = [](uint32_t z) -> uint32_t { return ((z >> 7) | (z >> 14) | (z >> 21) | (z >> 28)) & 0xFu; };   // bit 7 of each byte -> 4 bits
-		auto zero7 = [](uint32_t v) -> uint32_t { return ~(((v & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | v) & 0x80808080u; };   // bit 7 of every byte that is 0 (exact)
-#pragma unroll
-		for (int j = 0; j < 16; j++) {
-			const uint32_t w = s_b[lane * FROW + j];
-			const uint32_t zl = zero7(w ^ 0x4E4E4E4Eu), zc = zero7(w ^ 0x5E5E5E5Eu), zn = zero7(w ^ 0x2F2F2F2Fu);
-			const unsigned long long nl = nib(zl), nc = nib(zc);
-			L |= nl << (4 * j); C |= nc << (4 * j);
-			F |= (nl | nc | (unsigned long long)nib(zn)) << (4 * j);
-			if (M512) E |= (unsigned long long)nib(((w & 0x7F7F7F7Fu) + 0x01010101u) & 0x80808080u) << (4 * j);   // (byte & 0x7f) == 127
-		}
-		{
-			const long nv = (long)bpos + 1 - cb;                   // bytes of the piece at positions <= bpos: only those are nodes
-			const unsigned long long ok = nv <= 0 ? 0ull : (nv < 64 ? (1ull << nv) - 1ull : ~0ull);
-			F &= ok;
-			// run skipping (below) only takes blocks that end at or before bpos: COPY at positions < bpos, two-byte FILL at positions < bpos - 1
-			C &= ok >> 1;
-			L &= ok >> 2;
-		}
-		const bool more = cb + FC <= (long)bpos;               // the stream goes on behind this piece
-		unsigned long long En = 0;                             // escape codes of the piece behind (a NORMAL body spills <= 33 bytes)
-		if (M512) {
-			const uint32_t lo = (uint32_t)__shfl_down((int)(uint32_t)E, 1, 64), hi = (uint32_t)__shfl_down((int)(uint32_t)(E >> 32), 1, 64);
-			En = lane < 63 ? ((unsigned long long)hi << 32 | lo) : 0ull;
-			L &= ~((E >> 1) | (En << 63));                     // FILL whose index byte is not an escape code: two bytes
-		}
-		const int first = forced != FX_UNSET ? FH : 0;          // first lane that walks (its entry: forced, or speculative)
-		const bool walker = lane >= first && lane < 63 && cb >= 0;
-		const uint32_t* mine = s_b + lane * FROW;
-		unsigned long long V = 0, Q = 0;                       // entries / nodes of the lane's walk
-		uint32_t xo = FX_UNSET, applied = FX_UNSET;
-		uint32_t want = (lane == first && forced != FX_UNSET) ? forced : FX_SLIDE;
-		const unsigned long long EVEN = 0x5555555555555555ull;
-		for (int round = 0; round < 66; round++) {
-			const bool need = walker && want != applied;
-			if (__ballot(need) == 0) break;
-			// ---- apply the entry `want`: trim the walk the lane has, or walk from the entry until it merges / leaves
-			bool go = false;
-			uint32_t q = 0, res = xo;
-			unsigned long long Vw = 0, Qw = 0;
-			if (need) {
-				applied = want;
-				if (want == FX_END) { V = 0; Q = 0; res = FX_END; }
-				else {
-					const uint32_t x = want == FX_SLIDE ? 0u : want;
-					Vw = want == FX_SLIDE ? 0ull : 1ull << x;
-					const unsigned long long m = F >> x;
-					if (m == 0) { V = Vw; Q = 0; res = more ? FX_SLIDE : FX_END; }
-					else {
-						q = x + ctz64(m);
-						if ((Q >> q) & 1ull) { V = Vw | (V & above(q)); Q &= ~0ull << q; }   // same chain from q on, same exit
-						else go = true;
-					}
-				}
-			}
-			// The walk, written without divergent branches (selects on every lane).  One step takes a whole RUN of blocks of
-			// the same kind when it can: consecutive COPY bytes, or two-byte FILLs back to back -- up to where the old walk
-			// has a node (the merge is found by the next step).
-			uint32_t wres = FX_UNSET;
-			for (;;) {
-				if (__ballot(go) == 0) break;
-				const unsigned long long Qq = Q >> q;
-				const bool merged = go && (Qq & 1ull);
-				wres = merged ? FX_MERGE + q : wres;
-				go = go && !merged;
-				const uint32_t d0 = mine[q >> 2], d1 = mine[(q >> 2) + 1];       // (dword 16 of a piece = pad, only read for its byte 64 = ...)
-				const uint32_t d1n = mine[FROW];                                   // ... the first dword of the piece behind
-				const uint32_t two = __builtin_amdgcn_alignbyte((q >> 2) == 15u ? d1n : d1, d0, q & 3u);
-				const uint32_t t = two & 0xFFu;
-				const bool isN = t == NORMAL_FLAG, isC = t == COPY_FLAG;
-				// run lengths (>= 1 for a COPY node; 0 for a FILL node that is not of the two-byte, inside-bpos kind)
-				const unsigned long long oldn = Qq & ~1ull;                       // old nodes behind q
-				const uint32_t rc = min(ctz64z(~(C >> q)), ctz64z(oldn));
-				const uint32_t rl = min(ctz64z(~(L >> q) & EVEN), ctz64z(oldn & EVEN)) >> 1;
-				uint32_t e;                                                        // end of the step
-				unsigned long long qm;                                             // the nodes it takes, as a mask from q
-				if (isC && rc > 0) { e = q + rc; qm = rc >= 64u ? ~0ull : (1ull << rc) - 1ull; }
-				else if (!isC && !isN && rl > 0) { e = q + 2u * rl; qm = (rl >= 32u ? ~0ull : (1ull << (2u * rl)) - 1ull) & EVEN; }
-				else { e = q + (isC ? 1u : 2u + ((M512 && ((two >> 8) & 0x7Fu) == 127u) ? 1u : 0u)); qm = 1ull; }
-				// NORMAL lengths for many lanes at once (16 dependent steps): when enough lanes wait, or nobody else moves
-				const unsigned long long pm = __ballot(go && isN), am = __ballot(go && !isN);
-				const bool doN = pm != 0 && (am == 0 || __popcll(pm) >= 16);
-				if (doN) {
-					uint32_t len = 16;
-					if (M512) {
-						const uint32_t q1 = q + 1u;
-						const uint32_t m = (uint32_t)((q1 < 64u ? E >> q1 : 0ull) | (En << (63u - q)));
-						uint32_t pos = 0;
-#pragma unroll
-						for (int i = 0; i < 16; i++) pos += 1u + ((m >> pos) & 1u);
-						len = pos;
-					}
-					if (isN) { e = q + 1u + len; qm = 1ull; }
-				}
-				const bool adv = go && (!isN || doN);
-				const bool over = cb + (long)e > (long)bpos;                       // entered, not counted: the chain ends
-				const bool cnt = adv && !over;
-				const unsigned long long qbits = qm << q;
-				Qw |= cnt ? qbits : 0ull;
-				// entries: one behind every node taken (at its end) -- those at byte 64 and beyond belong to the next piece
-				unsigned long long vb;
-				if (qm == 1ull) vb = e < 64u ? 1ull << e : 0ull;
-				else vb = isC ? qbits << 1 : qbits << 2;
-				Vw |= cnt ? vb : 0ull;
-				const unsigned long long m = e < 64u ? F >> e : 0ull;
-				const bool inside = cnt && e < 64u && m != 0;
-				const uint32_t stop = over ? FX_END : (e >= 64u ? e - 64u : (more ? FX_SLIDE : FX_END));
-				wres = (adv && !inside) ? stop : wres;
-				q = inside ? e + ctz64(m) : q;
-				go = go && (!adv || inside);
-			}
-			if (need && wres != FX_UNSET) {
-				if (wres >= FX_MERGE) {
-					const uint32_t mq = wres - FX_MERGE;
-					V = Vw | (V & above(mq)); Q = Qw | (Q & (~0ull << mq));
-				} else { V = Vw; Q = Qw; res = wres; }
-			}
-			if (need) xo = res;
-			// ---- next round: every lane's true entry is the exit of the lane before it
-			const uint32_t px = (uint32_t)__shfl_up((int)xo, 1, 64);
-			if (walker && lane > first) want = px;
-		}
-		// ---- results
-		const bool own = lane >= FH && lane < 63;
-		if (own) A.vm[((size_t)f * A.maxR + r) * FOWN + (lane - FH)] = walker ? V : 0ull;
-		const uint32_t n = wave_sum(own && walker ? (uint32_t)__popcll(V) : 0u);
-		const uint32_t ein = forced != FX_UNSET ? forced : (uint32_t)__builtin_amdgcn_readlane((int)xo, FH - 1);
-		const uint32_t xout = (uint32_t)__builtin_amdgcn_readlane((int)xo, 62);
-		if (lane == 0) *rec = make_uint4(ein, xout, n, 0u);
-		wave_lds_sync();
-	}
+	for (uint32_t r = blockIdx.x; r < nreg; r += gridDim.x)
+		fp_walk_region<M512>(A, s_b, f, r, r == 0 ? 0u : FX_UNSET, bpos, lane);   // block 0 is entered at byte 0
 }
 
-// one wave per frame: prove the regions (see above), force the entries of those that are not, or number the blocks
-__global__ __launch_bounds__(64) void k_fp_scan(FpArgs A)
+// one wave per frame: prove the regions (see above), walk again those that are not, number the blocks
+template <bool M512>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_fp_finish(FpArgs A)
 {
+	__shared__ uint32_t s_b[FP_LDS];
 	const uint32_t f = blockIdx.x;
 	const int lane = threadIdx.x;
-	if (A.pass > 0 && A.fstate[f] != FS_TODO) return;
-	const uint32_t nreg = min(A.bpos[f] / FRB + 1u, A.maxR);
+	const uint32_t bpos = A.bpos[f];
+	const uint32_t nreg = min(bpos / FRB + 1u, A.maxR);
 	uint4* rec = A.rec + (size_t)f * A.maxR;
-	uint32_t xprev = 0, nbad = 0;                              // exit of the region before (region 0: entry at byte 0)
-	for (uint32_t r0 = 0; r0 < nreg; r0 += 64) {
-		const uint32_t r = r0 + lane;
-		uint4 v = make_uint4(0, 0, 0, 0);
-		if (r < nreg) v = rec[r];
-		uint32_t xp = (uint32_t)__shfl_up((int)v.y, 1, 64);
-		if (lane == 0) xp = xprev;
-		const bool bad = r < nreg && v.x != xp;
-		if (bad && A.pass < (uint32_t)FP_REPAIRS) { v.x = xp; v.w = 1u; rec[r] = v; }
-		nbad += (uint32_t)__popcll(__ballot(bad));
-		xprev = (uint32_t)__builtin_amdgcn_readlane((int)v.y, 63 < nreg - r0 - 1 ? 63 : (int)(nreg - r0 - 1));
-	}
-	if (nbad) {
-		if (lane == 0) A.fstate[f] = A.pass < (uint32_t)FP_REPAIRS ? FS_TODO : FS_BAD;
-		return;
+	// the first region at or behind `start` whose entry is not the exit of the region before it is walked again with that
+	// exit forced; its own exit may have changed, so the search goes on right behind it
+	int budget = FP_REPAIRS;
+	for (uint32_t start = 1;;) {
+		uint32_t bad = 0xFFFFFFFFu;
+		for (uint32_t r0 = start & ~63u; r0 < nreg && bad == 0xFFFFFFFFu; r0 += 64) {
+			const uint32_t r = r0 + lane;
+			const bool in = r < nreg && r >= start;
+			const uint32_t x = in ? __hip_atomic_load(&rec[r].x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+			const uint32_t yp = in ? __hip_atomic_load(&rec[r - 1].y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+			const unsigned long long bm = __ballot(in && x != yp);
+			if (bm) bad = r0 + ctz64(bm);
+		}
+		if (bad == 0xFFFFFFFFu) break;
+		if (budget-- == 0) {
+			if (lane == 0) A.fstate[f] = FS_BAD;
+			return;
+		}
+		const uint32_t want = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&rec[bad - 1].y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+		fp_walk_region<M512>(A, s_b, f, bad, want, bpos, lane);
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+		start = bad + 1;
 	}
 	uint32_t run = 0;
 	for (uint32_t r0 = 0; r0 < nreg; r0 += 64) {
 		const uint32_t r = r0 + lane;
-		const uint32_t n = r < nreg ? rec[r].z : 0u;
+		const uint32_t n = r < nreg ? __hip_atomic_load(&rec[r].z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
 		const uint32_t incl = wave_incl_scan(n, lane);
 		if (r < nreg) A.kb[(size_t)f * A.maxR + r] = run + incl - n;
 		run += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
@@ -1510,31 +1519,29 @@ __global__ __launch_bounds__(64) void k_fp_scan(FpArgs A)
 	if (lane == 0) { A.fstate[f] = FS_OK; A.nentered[f] = run < A.nblk ? run : A.nblk; }
 }
 
-// entry bitmaps -> offsets[]: lane = piece lists its set bits into the region's row in LDS, the row goes out coalesced
+// entry bitmaps -> offsets[]: per piece, the lanes whose bit is set write their byte position at the rank of the bit
+// (consecutive lanes, consecutive words: one partial row per piece)
 __global__ __launch_bounds__(64) void k_fp_expand(FpArgs A)
 {
-	__shared__ uint16_t s_pos[FRB];
 	const int lane = threadIdx.x;
 	const uint32_t f = blockIdx.y;
 	if (A.fstate[f] != FS_OK) return;
 	const uint32_t nreg = min(A.bpos[f] / FRB + 1u, A.maxR);
 	uint32_t* off = A.offsets + (size_t)f * A.nblk;
 	for (uint32_t r = blockIdx.x; r < nreg; r += gridDim.x) {
-		const uint32_t kb = A.kb[(size_t)f * A.maxR + r];
+		uint32_t kb = A.kb[(size_t)f * A.maxR + r];
 		if (kb >= A.nblk) break;                                // (uniform) blocks beyond the frame are never entered
-		unsigned long long V = lane < FOWN ? A.vm[((size_t)f * A.maxR + r) * FOWN + lane] : 0ull;
-		const uint32_t n = (uint32_t)__popcll(V);
-		const uint32_t incl = wave_incl_scan(n, lane);
-		const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-		uint32_t j = incl - n;
-		while (V) {
-			s_pos[j++] = (uint16_t)(lane * FC + ctz64(V));
-			V &= V - 1ull;
+		const unsigned long long V = lane < FOWN ? A.vm[((size_t)f * A.maxR + r) * FOWN + lane] : 0ull;
+		const uint32_t vlo = (uint32_t)V, vhi = (uint32_t)(V >> 32);
+		const uint32_t base = r * FRB + lane;
+#pragma unroll 4
+		for (int c = 0; c < FOWN; c++) {
+			const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)vlo, c), hi = (uint32_t)__builtin_amdgcn_readlane((int)vhi, c);
+			const unsigned long long Vc = (unsigned long long)hi << 32 | lo;
+			const uint32_t k = kb + __builtin_amdgcn_mbcnt_hi(hi, __builtin_amdgcn_mbcnt_lo(lo, 0u));
+			if (((Vc >> lane) & 1ull) && k < A.nblk) off[k] = base + (uint32_t)c * FC;
+			kb += (uint32_t)__popcll(Vc);
 		}
-		wave_lds_sync();
-		for (uint32_t i = lane; i < tot; i += 64)
-			if (kb + i < A.nblk) off[kb + i] = r * FRB + s_pos[i];
-		wave_lds_sync();
 	}
 }
 
@@ -2473,14 +2480,12 @@ static int parse_launch(agmv_hip_ctx* c, const uint8_t* d_bits, size_t stride, c
 	if (gx > maxR) gx = (uint32_t)maxR;
 	if (gx < 1) gx = 1;
 	const dim3 grid(gx, n_frames);
-	for (uint32_t pass = 0; pass <= (uint32_t)FP_REPAIRS; pass++) {
-		A.pass = pass;
-		if (c->mode512) hipLaunchKernelGGL(k_fp_walk<true>, grid, dim3(64), 0, s, A);
-		else            hipLaunchKernelGGL(k_fp_walk<false>, grid, dim3(64), 0, s, A);
-		CK(hipGetLastError());
-		hipLaunchKernelGGL(k_fp_scan, dim3(n_frames), dim3(64), 0, s, A);
-		CK(hipGetLastError());
-	}
+	if (c->mode512) hipLaunchKernelGGL(k_fp_walk<true>, grid, dim3(64), 0, s, A);
+	else            hipLaunchKernelGGL(k_fp_walk<false>, grid, dim3(64), 0, s, A);
+	CK(hipGetLastError());
+	if (c->mode512) hipLaunchKernelGGL(k_fp_finish<true>, dim3(n_frames), dim3(64), 0, s, A);
+	else            hipLaunchKernelGGL(k_fp_finish<false>, dim3(n_frames), dim3(64), 0, s, A);
+	CK(hipGetLastError());
 	hipLaunchKernelGGL(k_fp_expand, grid, dim3(64), 0, s, A);
 	CK(hipGetLastError());
 	c->d_fp_fstate = A.fstate; c->fp_frames = n_frames;

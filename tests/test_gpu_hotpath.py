@@ -431,12 +431,16 @@ def test_parallel_parser_matches_serial_walk(torch, hip, monkeypatch):
         o_ser, n_ser = hip.parse_dev(out, sizes, n, W, H)
         torch.cuda.synchronize()
         ne = n_ser.cpu().numpy()
-        monkeypatch.delenv("AGMV_HIP_PARSE")
-        o_par, n_par = hip.parse_dev(out, sizes, n, W, H)
-        torch.cuda.synchronize()
-        assert torch.equal(n_ser, n_par), (n_ser.cpu().numpy(), n_par.cpu().numpy())
-        for f in range(n):
-            assert torch.equal(o_ser[f, :ne[f]], o_par[f, :ne[f]]), "mode512=%s frame %d (nentered %d of %d)" % (mode512, f, ne[f], nblk)
+        for how in (None, "robust"):                          # speculative walks + proof (default), the map/stitch/emit kernels alone
+            if how:
+                monkeypatch.setenv("AGMV_HIP_PARSE", how)
+            else:
+                monkeypatch.delenv("AGMV_HIP_PARSE")
+            o_par, n_par = hip.parse_dev(out, sizes, n, W, H)
+            torch.cuda.synchronize()
+            assert torch.equal(n_ser, n_par), (how, n_ser.cpu().numpy(), n_par.cpu().numpy())
+            for f in range(n):
+                assert torch.equal(o_ser[f, :ne[f]], o_par[f, :ne[f]]), "%s mode512=%s frame %d (nentered %d of %d)" % (how, mode512, f, ne[f], nblk)
         monkeypatch.delenv("AGMV_HIP_PARSE", raising=False)
 
 
@@ -471,13 +475,18 @@ def test_fuzz_parser_random_bytes(torch, hip, monkeypatch, seed):
     monkeypatch.setenv("AGMV_HIP_PARSE", "serial")
     o_ser, n_ser = hip.parse_dev(dbits, dbpos, n, W, H)
     torch.cuda.synchronize()
-    monkeypatch.delenv("AGMV_HIP_PARSE")
-    o_par, n_par = hip.parse_dev(dbits, dbpos, n, W, H)
-    torch.cuda.synchronize()
     ne = n_ser.cpu().numpy()
-    assert torch.equal(n_ser, n_par), (ne, n_par.cpu().numpy(), bpos)
-    for f in range(n):
-        assert torch.equal(o_ser[f, :ne[f]], o_par[f, :ne[f]]), "frame %d bpos %d nentered %d (%dx%d mode512=%s stride %d)" % (f, bpos[f], ne[f], W, H, mode512, stride)
+    for how in (None, "robust"):
+        if how:
+            monkeypatch.setenv("AGMV_HIP_PARSE", how)
+        else:
+            monkeypatch.delenv("AGMV_HIP_PARSE")
+        o_par, n_par = hip.parse_dev(dbits, dbpos, n, W, H)
+        torch.cuda.synchronize()
+        assert torch.equal(n_ser, n_par), (how, ne, n_par.cpu().numpy(), bpos)
+        for f in range(n):
+            assert torch.equal(o_ser[f, :ne[f]], o_par[f, :ne[f]]), "%s frame %d bpos %d nentered %d (%dx%d mode512=%s stride %d)" % (how, f, bpos[f], ne[f], W, H, mode512, stride)
+    monkeypatch.delenv("AGMV_HIP_PARSE", raising=False)
     # and the reconstruct step must agree with itself on both tables (fix-up path: almost every block is stale here)
     a = hip.decode_dev(dbits, dbpos, o_ser, n_ser, n, W, H, 0)
     b = hip.decode_dev(dbits, dbpos, o_par, n_par, n, W, H, 0)
@@ -487,6 +496,56 @@ def test_fuzz_parser_random_bytes(torch, hip, monkeypatch, seed):
         got = to_u32(b).reshape(n, -1)
         for f in range(n):
             assert (got[f] == exp[f]).all(), "pixels frame %d bpos %d (%dx%d mode512=%s)" % (f, bpos[f], W, H, mode512)
+
+
+@pytest.mark.parametrize("mode512", [True, False])
+def test_parser_proof_repair_and_fallback(torch, hip, monkeypatch, mode512):
+    """The speculative parser on streams built to defeat the speculation.  "4E 4E 4E 4E ..." is a run of two-byte FILLs
+    whose index byte is itself a flag value: a walk that starts on the wrong byte parity follows a second chain through
+    the whole run and never merges.  (a) a clean encoder frame: proven as walked; (b) a few such runs across region
+    boundaries inside COPY filler: the regions behind them are walked again with a forced entry and the frame is proven;
+    (c) a whole frame of it: given up, parsed by the map/stitch/emit kernels.  All against the one-lane serial walk."""
+    W, H = 1920, 1080
+    nblk = W * H // 16
+    p0, p1 = S.content_palettes([S.synth_frame(W, H, 0)])
+    hip.set_palette(p0, p1, mode512)
+    out, sizes = hip.encode_dev(hip.synth_dev(W, H, 0, 1), 1, W, H)
+    hip.check()
+    stride = out.shape[1]
+    a = out[0].cpu().numpy()
+    region = 59 * 64
+    b = np.full(stride, 0x5E, np.uint8)                       # COPY filler, one block per byte
+    pos, blocks = 0, 0
+    for k in (1, 2, 3, 5, 8, 13, 14, 15):                     # runs of 500 FILLs that start 775 bytes before a region boundary, on an odd byte
+        start = k * region - 775
+        assert start > pos and start % 2 == 1
+        blocks += start - pos
+        b[start:start + 1000] = 0x4E
+        pos = start + 1000
+        blocks += 500
+    usize_b = pos + (nblk - blocks)
+    assert usize_b < stride - 64
+    c = np.full(stride, 0x4E, np.uint8)                       # one COPY, then FILL(entry 0x4E) for every other block: the true chain is on odd bytes
+    c[0] = 0x5E
+    usize_c = 1 + 2 * (nblk - 1)
+    bits = torch.from_numpy(np.stack([a, b, c])).cuda()
+    bpos = torch.tensor([int(sizes[0]), usize_b, usize_c], dtype=torch.int32, device="cuda")
+    monkeypatch.setenv("AGMV_HIP_PARSE", "serial")
+    o_ser, n_ser = hip.parse_dev(bits, bpos, 3, W, H)
+    torch.cuda.synchronize()
+    assert n_ser.cpu().tolist() == [nblk, nblk, nblk]
+    monkeypatch.delenv("AGMV_HIP_PARSE")
+    o_par, n_par = hip.parse_dev(bits, bpos, 3, W, H)
+    torch.cuda.synchronize()
+    assert hip.parse_fallback_frames() == 1                   # (c) only
+    assert torch.equal(n_ser, n_par)
+    assert torch.equal(o_ser, o_par)
+    # the same three frames through the ranges-of-GOPs pipeline (parse || reconstruct) and through the two separate calls
+    dec_a = hip.decode_dev(bits, bpos, o_par, n_par, 3, W, H)
+    dec_b, o_b, n_b = hip.parse_decode_dev(bits, bpos, 3, W, H)
+    torch.cuda.synchronize()
+    assert torch.equal(dec_a, dec_b) and torch.equal(o_b, o_par) and torch.equal(n_b, n_par)
+
 
 
 # ------------------------------------------------------------------------------- helpers
