@@ -1519,29 +1519,45 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
 	if (lane == 0) { A.fstate[f] = FS_OK; A.nentered[f] = run < A.nblk ? run : A.nblk; }
 }
 
-// entry bitmaps -> offsets[]: per piece, the lanes whose bit is set write their byte position at the rank of the bit
-// (consecutive lanes, consecutive words: one partial row per piece)
+// entry bitmaps -> offsets[]: the region's entries are listed in LDS (byte position inside the region, in order) and go
+// out as coalesced rows.  Listing: sparse bitmaps -- every lane walks the set bits of its own piece; dense ones (runs of
+// COPY: 64 entries in a piece) -- piece by piece, the lanes whose bit is set write at the rank of their bit.
 __global__ __launch_bounds__(64) void k_fp_expand(FpArgs A)
 {
+	__shared__ uint16_t s_pos[FRB];
 	const int lane = threadIdx.x;
 	const uint32_t f = blockIdx.y;
 	if (A.fstate[f] != FS_OK) return;
 	const uint32_t nreg = min(A.bpos[f] / FRB + 1u, A.maxR);
 	uint32_t* off = A.offsets + (size_t)f * A.nblk;
 	for (uint32_t r = blockIdx.x; r < nreg; r += gridDim.x) {
-		uint32_t kb = A.kb[(size_t)f * A.maxR + r];
+		const uint32_t kb = A.kb[(size_t)f * A.maxR + r];
 		if (kb >= A.nblk) break;                                // (uniform) blocks beyond the frame are never entered
-		const unsigned long long V = lane < FOWN ? A.vm[((size_t)f * A.maxR + r) * FOWN + lane] : 0ull;
-		const uint32_t vlo = (uint32_t)V, vhi = (uint32_t)(V >> 32);
-		const uint32_t base = r * FRB + lane;
+		unsigned long long V = lane < FOWN ? A.vm[((size_t)f * A.maxR + r) * FOWN + lane] : 0ull;
+		const uint32_t n = (uint32_t)__popcll(V);
+		const uint32_t incl = wave_incl_scan(n, lane);
+		const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+		if (__ballot(n > 40u) == 0) {
+			uint32_t j = incl - n;
+			while (V) {
+				s_pos[j++] = (uint16_t)(lane * FC + ctz64(V));
+				V &= V - 1ull;
+			}
+		} else {
+			const uint32_t vlo = (uint32_t)V, vhi = (uint32_t)(V >> 32);
+			uint32_t j = 0;
 #pragma unroll 4
-		for (int c = 0; c < FOWN; c++) {
-			const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)vlo, c), hi = (uint32_t)__builtin_amdgcn_readlane((int)vhi, c);
-			const unsigned long long Vc = (unsigned long long)hi << 32 | lo;
-			const uint32_t k = kb + __builtin_amdgcn_mbcnt_hi(hi, __builtin_amdgcn_mbcnt_lo(lo, 0u));
-			if (((Vc >> lane) & 1ull) && k < A.nblk) off[k] = base + (uint32_t)c * FC;
-			kb += (uint32_t)__popcll(Vc);
+			for (int c = 0; c < FOWN; c++) {
+				const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)vlo, c), hi = (uint32_t)__builtin_amdgcn_readlane((int)vhi, c);
+				const unsigned long long Vc = (unsigned long long)hi << 32 | lo;
+				if ((Vc >> lane) & 1ull) s_pos[j + __builtin_amdgcn_mbcnt_hi(hi, __builtin_amdgcn_mbcnt_lo(lo, 0u))] = (uint16_t)(c * FC + lane);
+				j += (uint32_t)__popcll(Vc);
+			}
 		}
+		wave_lds_sync();
+		for (uint32_t i = lane; i < tot; i += 64)
+			if (kb + i < A.nblk) off[kb + i] = r * FRB + s_pos[i];
+		wave_lds_sync();
 	}
 }
 
