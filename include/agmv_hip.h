@@ -138,11 +138,11 @@ int agmv_hip_decode_frames_dev(agmv_hip_ctx* ctx, const uint8_t* d_bits, size_t 
    long run of FILL blocks carries a flag-valued index; damaged streams typically land here).  A statistic: the
    outputs are the same either way.  Synchronises the stream; negative on error. */
 int agmv_hip_parse_fallback_frames(agmv_hip_ctx* ctx, void* stream);
-/* Both steps as ONE call, overlapped: the batch is cut into ranges of GOPs, the parser kernels (bound by instruction
-   issue, little memory traffic) run on a stream the context owns and the reconstruction of a range (bound by its pixel
-   stores) waits only for the parse of that range, so the parse of the next range shares the CUs with it.  Same inputs,
-   same outputs (d_offsets / d_nentered are written as by agmv_hip_parse_frames_dev), same pixels; everything is ordered
-   after the work already on `stream`, and `stream` is complete only when the whole call is. */
+/* Both steps as ONE call.  Same inputs, same outputs (d_offsets / d_nentered are written as by
+   agmv_hip_parse_frames_dev), same pixels.  With AGMV_DEC_SLICES=n in the environment the batch is cut into n ranges of
+   GOPs, the parser runs on a stream the context owns and the reconstruction of a range waits only for the parse of that
+   range (measured: no gain on MI355X, the default is one range).  Everything is ordered after the work already on
+   `stream`, and `stream` is complete only when the whole call is. */
 int agmv_hip_parse_decode_frames_dev(agmv_hip_ctx* ctx, const uint8_t* d_bits, size_t bits_stride,
                                      const uint32_t* d_bpos, uint32_t n_frames, uint32_t w, uint32_t h,
                                      uint32_t first_frame_count, uint32_t* d_offsets, uint32_t* d_nentered,

@@ -2618,10 +2618,10 @@ extern "C" int agmv_hip_decode_frames_dev(agmv_hip_ctx* c, const uint8_t* d_bits
 	return 0;
 }
 
-// Parse + reconstruct as ONE call.  The parser kernels are bound by instruction issue and move little data, k_decode is
-// bound by its pixel stores and issues little: the batch is cut into ranges of GOPs, the parser runs on a stream of the
-// context's own, and the reconstruction of range k (caller's stream) waits only for the parse of range k, so the parse
-// of range k+1 shares the CUs with it.  k_fixup needs every frame's offsets and runs last.
+// Parse + reconstruct as ONE call; optionally (AGMV_DEC_SLICES=n) cut into n ranges of GOPs with the parser on a stream of
+// the context's own, so that the parse of range k+1 runs beside the reconstruction of range k (k_fixup needs every
+// frame's offsets and runs last).  Measured (profiles/r02/k_decode_experiments.txt): the kernels do run side by side but
+// take from each other what they gain -- k_decode needs its full occupancy -- so the default is one range.
 extern "C" int agmv_hip_parse_decode_frames_dev(agmv_hip_ctx* c, const uint8_t* d_bits, size_t stride, const uint32_t* d_bpos,
                                                 uint32_t n_frames, uint32_t w, uint32_t h, uint32_t first_fc,
                                                 uint32_t* d_offsets, uint32_t* d_nentered, uint32_t* d_out,
@@ -2633,11 +2633,9 @@ extern "C" int agmv_hip_parse_decode_frames_dev(agmv_hip_ctx* c, const uint8_t* 
 	hipStream_t s = (hipStream_t)stream;
 	DecArgs A;
 	if (decode_prepare(c, A, d_bits, stride, d_bpos, d_offsets, d_nentered, n_frames, w, h, first_fc, d_out, d_prev, d_prev_iframe, s)) return -1;
-	// ranges: at least DEC_SLICE_MIN GOPs each (a launch must still fill the chip), at most DEC_MAX_SLICES of them
-	uint32_t nsl = 8;
-	if (getenv("AGMV_DEC_SLICES")) nsl = (uint32_t)atoi(getenv("AGMV_DEC_SLICES"));   // tuning aid
-	const uint32_t min_groups = (uint32_t)(((size_t)c->n_cu * 16 + A.tpf - 1) / A.tpf);   // ~16 workgroups per CU and launch
-	if (nsl > A.n_groups / (min_groups ? min_groups : 1u)) nsl = A.n_groups / (min_groups ? min_groups : 1u);
+	uint32_t nsl = 1;
+	if (getenv("AGMV_DEC_SLICES")) nsl = (uint32_t)atoi(getenv("AGMV_DEC_SLICES"));
+	if (nsl > A.n_groups) nsl = A.n_groups;
 	if (nsl > (uint32_t)DEC_MAX_SLICES) nsl = DEC_MAX_SLICES;
 	if (nsl < 1) nsl = 1;
 	const uint32_t gps = (A.n_groups + nsl - 1) / nsl;         // GOPs per range

@@ -547,6 +547,33 @@ def test_parser_proof_repair_and_fallback(torch, hip, monkeypatch, mode512):
     assert torch.equal(dec_a, dec_b) and torch.equal(o_b, o_par) and torch.equal(n_b, n_par)
 
 
+@pytest.mark.parametrize("first_fc", [0, 2])
+def test_parse_decode_in_ranges(torch, hip, monkeypatch, first_fc):
+    """agmv_hip_parse_decode_frames_dev cut into ranges of GOPs (parser on its own stream, reconstruction of a range behind
+    the parse of that range) gives the pixels, offsets and counts of the two separate calls -- also when the batch starts
+    inside a GOP and carries decoder state in."""
+    W, H, T = 320, 240, 41
+    p0, p1 = S.content_palettes([S.synth_frame(W, H, 0)])
+    hip.set_palette(p0, p1, True)
+    frames = hip.synth_dev(W, H, 0, T)
+    out, sizes = hip.encode_dev(frames, T, W, H, first_fc, ientries=torch.zeros(W * H, dtype=torch.int16, device="cuda"))
+    hip.check()
+    sizes[7] = sizes[7] // 2                                   # a truncated frame: stale blocks, k_fixup has work
+    prev = torch.randint(0, 1 << 24, (H, W), dtype=torch.int32, device="cuda")
+    previ = torch.randint(0, 1 << 24, (H, W), dtype=torch.int32, device="cuda")
+    offs, nent = hip.parse_dev(out, sizes, T, W, H)
+    ref = hip.decode_dev(out, sizes, offs, nent, T, W, H, first_fc, prev=prev, prev_iframe=previ)
+    torch.cuda.synchronize()
+    for ns in ("1", "3", "5", "32"):
+        monkeypatch.setenv("AGMV_DEC_SLICES", ns)
+        dec, o2, n2 = hip.parse_decode_dev(out, sizes, T, W, H, first_fc, prev=prev, prev_iframe=previ)
+        torch.cuda.synchronize()
+        assert torch.equal(n2, nent), ns
+        assert torch.equal(dec, ref), ns
+        idx = torch.arange(W * H // 16, device="cuda")[None, :] < nent[:, None]
+        assert torch.equal(o2[idx], offs[idx]), ns
+
+
 
 # ------------------------------------------------------------------------------- helpers
 def test_synth_interp_histogram(torch, hip):
