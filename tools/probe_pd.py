@@ -20,11 +20,16 @@ for _ in range(5):
     hip.decode_dev(out, sizes, offs, nent, T, W, H, out=dec); td.append(hip.last_kernel_ms(2))
 ref = dec.clone(); ref_off = offs.clone()
 print("separate: parse %.3f + decode %.3f = %.3f ms (%d frames)" % (sorted(tp)[2], sorted(td)[2], sorted(tp)[2] + sorted(td)[2], T), flush=True)
-for ns in sys.argv[1:]:
+for arg in sys.argv[1:]:                                      # N or N:GX (GX = parser workgroups per frame, AGMV_PARSE_GX)
+    ns, _, gx = arg.partition(":")
     os.environ["AGMV_DEC_SLICES"] = ns
+    if gx:
+        os.environ["AGMV_PARSE_GX"] = gx
+    else:
+        os.environ.pop("AGMV_PARSE_GX", None)
     dec.zero_(); offs.zero_()
     ts = []
     for _ in range(5):
         hip.parse_decode_dev(out, sizes, T, W, H, out=dec, offsets=offs, nentered=nent); ts.append(hip.last_kernel_ms(3))
     ok = bool(torch.equal(dec, ref)) and bool(torch.equal(offs, ref_off))
-    print("slices %s: %.3f ms  same=%s" % (ns, sorted(ts)[2], ok), flush=True)
+    print("slices %s: %.3f ms  same=%s" % (arg, sorted(ts)[2], ok), flush=True)
