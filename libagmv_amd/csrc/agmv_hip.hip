@@ -1290,6 +1290,9 @@ constexpr int FRB = FOWN * FC;          // bytes a region owns
 constexpr int FROW = FC / 4 + 1;        // LDS dwords per piece (odd stride: no bank conflicts between the lanes' pieces)
 constexpr uint32_t FX_SLIDE = 64u, FX_END = 65u, FX_UNSET = 66u, FX_MERGE = 128u;
 constexpr int FP_REPAIRS = 24;          // regions of one frame walked again (serially, by the frame's wave) before the frame is given up
+#ifndef FP_NBATCH
+#define FP_NBATCH 1                     // lanes waiting at a NORMAL block before their lengths are computed together (1 / 4 / 8 / 16 / 32 measured the same: synth 0.185-0.191, NORMAL-heavy 0.400-0.419 ms per 256 frames)
+#endif
 constexpr int FP_LDS = 64 * FROW + 1;   // (+1: lane 63's look at "the piece behind" stays inside)
 
 struct FpArgs {
@@ -1415,10 +1418,12 @@ __device__ __forceinline__ void fp_walk_region(const FpArgs& A, uint32_t* s_b, u
 			uint32_t len1 = isC ? 1u : 2u + ((M512 && ((two >> 8) & 0x7Fu) == 127u) ? 1u : 0u);   // length of the block at q
 			uint32_t nrun = 1, qm = 1;                             // blocks taken; their nodes as a mask from q
 			if (isC && rc > 1u) { nrun = rc; qm = (1u << rc) - 1u; }
+#ifndef FP_NOFILLRUN
 			if (!isC && !isN && rl > 1u) { nrun = rl; qm = ((1u << (2u * rl)) - 1u) & 0x55555555u; }
-			// NORMAL lengths for many lanes at once (16 dependent steps): when enough lanes wait, or nobody else moves
+#endif
+			// NORMAL lengths (16 dependent steps), for all the lanes that wait at one (FP_NBATCH: or only once enough of them do)
 			const unsigned long long pm = __ballot(go && isN), am = __ballot(go && !isN);
-			const bool doN = pm != 0 && (am == 0 || __popcll(pm) >= 16);
+			const bool doN = pm != 0 && (am == 0 || __popcll(pm) >= FP_NBATCH);
 			if (doN) {
 				uint32_t len = 16;
 				if (M512) {

@@ -37,7 +37,10 @@ DRIVER = textwrap.dedent("""
 
 CASES = ["agmv_opt3_low_lzss_160x128", "agmv_opt1_mid_lzss_160x128", "agmv_opt2_low_lz77_160x128", "full_opt3_high_lzss_160x128",
          "agmv_gba1_low_lzss_320x240", "agmv_nds_low_lzss_320x240", "video_opt3_low_lzss_160x128",
-         "c2_agmv_opt3_low_lzss_320x240"]
+         "c2_agmv_opt3_low_lzss_320x240",
+         # BASELINE.json configs 4 / 5 in shape (tests/golden/make_golden_large.py): a 1080p source through the GBA scaler
+         # (121x81 read as 120x80, heavy PDIFS) and a 1280x720 OPT_III clip through AGMV_EncodeAGMV
+         "c4_agmv_gba1_low_lzss_1920x1080", "c5_agmv_opt3_low_lzss_1280x720"]
 
 
 @pytest.mark.parametrize("name", CASES)
