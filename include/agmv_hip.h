@@ -120,7 +120,10 @@ int agmv_hip_within2_count(agmv_hip_ctx* ctx, const uint32_t a[16], const uint32
  *   d_bpos[f]              : bitstream->pos after the LZ stage (may differ from usize).
  * agmv_hip_parse_frames_dev computes, per frame, the byte position at which each 4x4 block is
  * entered (d_offsets[f*nblk + k]) and how many blocks are entered before the reference raises
- * `escape` (d_nentered[f]).  agmv_hip_decode_frames_dev turns that into pixels:
+ * `escape` (d_nentered[f]) -- by speculative per-piece walks that are PROVEN per frame to be the serial parse, and by the
+ * map / stitch / emit kernels for the frames that cannot be proven (AGMV_HIP_PARSE=robust in the
+ * environment runs the latter alone, =serial a one-lane walk: debugging aids, same outputs).
+ * agmv_hip_decode_frames_dev turns that into pixels:
  * d_pix_out + f*w*h.  d_prev_frame / d_prev_iframe (w*h pixels, may be NULL = zeroed, the state
  * of a fresh decoder) are img_data / iframe->img_data before the first frame of the batch;
  * blocks the bitstream does not reach keep the previous frame's pixels (:229-232). */
