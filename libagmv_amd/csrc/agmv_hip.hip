@@ -608,6 +608,7 @@ __global__ __launch_bounds__(ENC_T, ENC_WPE) ENC_WAVES_ATTR void k_encode(EncArg
 #else
 #define PSTAMP(k) do { } while (0)
 #endif
+	uint32_t prof_sink = 0; (void)prof_sink;
 	auto body = [&](uint4 (&px)[4]) -> bool {                 // one item: consumes px and refills it with the item ENC_PFDEPTH ahead
 		EncGeo& g = cur.g;
 		const int f = cur.f;
@@ -713,10 +714,28 @@ __global__ __launch_bounds__(ENC_T, ENC_WPE) ENC_WAVES_ATTR void k_encode(EncArg
 			eq[k] = pxv[k] & 0x1FFu;
 #else
 			if (ENTRIES) eq[k] = pxv[k] & (M512 ? 0x1FFu : 0xFFu);
-			else eq[k] = (uint16_t)__builtin_amdgcn_raw_buffer_load_b16(lut_rs, LUT_OFF(pxv[k]), 0, ENC_LUTAUX);
+			else {
+				eq[k] = (uint16_t)__builtin_amdgcn_raw_buffer_load_b16(lut_rs, LUT_OFF(pxv[k]), 0, ENC_LUTAUX);
+			}
 #endif
 		}
 		PSTAMP(0);
+#ifdef ABL_SALU
+		{	// ablation: ABL_SALU extra scalar instructions per item (is scalar issue on the critical path?)
+			uint32_t sx = (uint32_t)it;
+#pragma unroll
+			for (int z = 0; z < ABL_SALU; z++) asm volatile("s_add_u32 %0, %0, 1" : "+s"(sx) :: "scc");
+			if (sx == 0x12345u) prof_sink = sx;
+		}
+#endif
+#ifdef ABL_VALU
+		{	// ablation: ABL_VALU extra (independent of everything) vector instructions per item
+			uint32_t vx = (uint32_t)lane;
+#pragma unroll
+			for (int z = 0; z < ABL_VALU; z++) asm volatile("v_add_u32 %0, %0, 1" : "+v"(vx));
+			if (vx == 0x12345u) prof_sink = vx;
+		}
+#endif
 		// issued right BEHIND the look-ups (the memory counter retires in order: ahead of them they would have to land
 		// before the first entry is usable), and before the wait for the entries
 #if ENC_PFLATE == 0
@@ -868,6 +887,9 @@ __global__ __launch_bounds__(ENC_T, ENC_WPE) ENC_WAVES_ATTR void k_encode(EncArg
 			if (!body(pxs[d])) goto done;
 	}
 done:;
+#if defined(ABL_SALU) || defined(ABL_VALU)
+	if (prof_sink == 0x12345u) A.ctrl[3] = prof_sink;
+#endif
 #ifdef ENC_PROF
 	if (lane == 0)
 		for (int k = 0; k < 11; k++) atomicAdd(A.ctrl + 32 + k, k == 10 ? prof[k] : prof[k] >> 6);
