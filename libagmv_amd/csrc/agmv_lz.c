@@ -7,9 +7,9 @@
  * 1080p frame).  What it computes is well defined: the LONGEST match (capped at 15 for LZSS, 255
  * for LZ77) whose start lies in [i-65535, i), and among equally long ones the EARLIEST start
  * (strict '>' while scanning oldest -> newest, src/agmv_encode.c:138).  Here:
- *   LZSS  for every length L = 3..15 a hash of L-grams whose buckets are FIFO queues of window
- *         positions; the first L (from 15 down) that has a verified hit is the match length and
- *         the queue front is the earliest start.  O(13) per byte.
+ *   LZSS  hashes of L-grams whose buckets are FIFO queues of window positions, for L = 3, 5, 8, 15: the longest of
+ *         those whose gram has a verified hit bounds the match length, one walk over that gram's occurrences
+ *         settles it; the queue order gives the earliest start (see lzss_run).
  *   LZ77  lengths 1..2 by the same queues, longer ones by a full walk of the 3-gram chain.
  * State is per call (the reference's is file-static), so frames compress on several host
  * threads; the FILE* entry points AGMV_LZSS/AGMV_LZ77 feed the shared AGMV_WriteBits like the
@@ -122,12 +122,47 @@ static inline void put_byte(sink* s, unsigned v)
 	else s->out[s->n++] = (u8)v;
 }
 
-/* ---- LZSS (reference src/agmv_encode.c:106-177) ---------------------------------------------*/
+/* ---- LZSS (reference src/agmv_encode.c:106-177) ---------------------------------------------
+ * Queues are kept for a FEW gram lengths only -- 3, 5, 8 and 15: four insertions per byte instead of thirteen, and the
+ * insertions are what the time goes to.  "An L-gram has an occurrence in the window" is monotone in L, so with queue
+ * lengths T[0] < T[1] < ... the longest match length L* is found from the top: the first T[k] whose gram occurs gives
+ * T[k] <= L* < T[k+1], and L* with its earliest start comes from one walk over ALL the occurrences of that T[k]-gram
+ * (oldest first, strictly longer wins: earliest among equals).  The 3-gram is probed first: most positions of noisy
+ * data have no match at all.  Measured on pre-LZ bitstreams of the synthetic clip / a NORMAL-heavy one (ms per ~0.5 MB,
+ * one core): all of 3..15: 113 / 166; {3,4,5,6,9,12,15}: 51 / 84; {3,5,8,15}: 32 / 48; {3,5,15}: 28 / 39 but 29 instead of
+ * 6 on three-symbol data (long walks over frequent 5-grams); {3,15}: 35 / 47 and 190.  Same bytes in every case. */
+#ifndef LZ_QSET
+#define LZ_QSET {3, 5, 8, 15}
+#endif
+static const int LZ_Q[] = LZ_QSET;
+#define LZ_NQ ((int)(sizeof(LZ_Q) / sizeof(LZ_Q[0])))
+
+/* longest match (>= L of q, <= cap) among all live occurrences >= lo of the L-gram at i; earliest start among the
+   longest; returns the length (0 = the gram does not occur) */
+static inline int gq_longest(const gq* q, const u8* d, int i, unsigned h, int lo, int cap, int* start)
+{
+	const gbkt* b = &q->b[h];
+	int p, best = 0;
+	if (!b->head) return 0;
+	p = b->head - 1;
+	for (;;) {
+		if (p >= lo && memcmp(d + p, d + i, (size_t)q->L) == 0) {
+			int j = q->L;
+			while (j < cap && d[p + j] == d[i + j]) j++;
+			if (j > best) { best = j; *start = p; if (best == cap) return best; }
+		}
+		if (p + 1 == b->tail) return best;
+		p += (int)((q->s[(unsigned)p & (RING - 1)].nxt - ((unsigned)p & (RING - 1))) & (RING - 1));
+	}
+}
+
 static u32 lzss_run(const u8* d, int n, sink* s)
 {
 	gq q[16];
-	int L, i = 0, ins = 0, outbits = 0;
-	for (L = 3; L <= 15; L++) gq_init(&q[L], L);
+	unsigned char isq[16];
+	int k, L, i = 0, ins = 0, outbits = 0;
+	memset(isq, 0, sizeof(isq));
+	for (k = 0; k < LZ_NQ; k++) { gq_init(&q[LZ_Q[k]], LZ_Q[k]); isq[LZ_Q[k]] = 1; }
 	while (i < n) {
 		int maxlen = n - i < 15 ? n - i : 15, lo = i - WIN, best = 0, start = 0;
 		unsigned hs[16], h;
@@ -138,14 +173,20 @@ static u32 lzss_run(const u8* d, int n, sink* s)
 			h = H_INIT;
 			for (L = 1; L <= top; L++) {
 				h = H_STEP(h, d[ins + L - 1]);
-				if (L >= 3) gq_insert_h(&q[L], ins, H_FOLD(h), old);
+				if (isq[L]) gq_insert_h(&q[L], ins, H_FOLD(h), old);
 			}
 		}
 		h = H_INIT;
 		for (L = 1; L <= maxlen; L++) { h = H_STEP(h, d[i + L - 1]); hs[L] = H_FOLD(h); }
-		for (L = maxlen; L >= 3; L--) {
-			int p = gq_find_h(&q[L], d, i, hs[L], lo);
-			if (p >= 0) { best = L; start = p; break; }
+		/* the shortest gram first (most positions of noisy data end here), then from the top */
+		if (maxlen >= 3 && (best = gq_longest(&q[3], d, i, hs[3], lo, maxlen < LZ_Q[1] - 1 ? maxlen : LZ_Q[1] - 1, &start)) > 0) {
+			for (k = LZ_NQ - 1; k >= 1; k--) {
+				const int Lk = LZ_Q[k], cap = k + 1 < LZ_NQ ? LZ_Q[k + 1] - 1 : 15;
+				int st, b;
+				if (maxlen < Lk) continue;
+				b = gq_longest(&q[Lk], d, i, hs[Lk], lo, maxlen < cap ? maxlen : cap, &st);
+				if (b > 0) { best = b; start = st; break; }
+			}
 		}
 		if (best < 3) {                                    /* literal: flag 1 + 8 bits */
 			put_bits(s, 1, 1); put_bits(s, d[i], 8);
@@ -155,7 +196,7 @@ static u32 lzss_run(const u8* d, int n, sink* s)
 			outbits += 21; i += best;
 		}
 	}
-	for (L = 3; L <= 15; L++) gq_free(&q[L]);
+	for (k = 0; k < LZ_NQ; k++) gq_free(&q[LZ_Q[k]]);
 	return (u32)((float)outbits / 8.0f);                   /* csize is computed in float, :176 */
 }
 
