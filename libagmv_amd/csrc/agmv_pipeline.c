@@ -683,7 +683,40 @@ static size_t scan_fourcc(const u8* d, size_t len, size_t pos, const char* cc)
 	return len;
 }
 
-/* the frame loop of AGMV_DecodeAGMV / AGMV_DecodeVideo on a file image: `pos` = first byte behind the header */
+/* the LZ stage of one frame on a pool thread: straight into the frame's row of the batch slab (the decoder copies only
+   from bytes it has written itself, src < bpos, so the row's old content does not matter) */
+typedef struct unlz { dpipe* d; int ver; const u8* payload; size_t avail, cap, used, chunk; uint32_t usize, csize, bpos; u8* row; unsigned* left; } unlz;
+
+static void unlz_task(void* p)
+{
+	unlz* j = (unlz*)p;
+	dpipe* d = j->d;
+	j->bpos = agmv_lz_decode_mem(j->ver, j->payload, j->avail, j->usize, j->csize, j->row, j->cap, &j->used);
+	pthread_mutex_lock(&d->mu);
+	if (--*j->left == 0) pthread_cond_broadcast(&d->cv);
+	pthread_mutex_unlock(&d->mu);
+}
+
+/* where the reference's reader stands behind a frame chunk at c whose LZ stage consumed `used` payload bytes (audio: AGMV_FindNextAudioChunk
+   + skip, out of scope) */
+static size_t behind_chunk(const u8* file, size_t len, size_t c, size_t used, int has_audio)
+{
+	size_t pos = c + 16 + used;
+	if (has_audio) {
+		size_t ac = scan_fourcc(file, len, pos, "AGAC");
+		if (ac + 8 <= len) pos = ac + 8 + (file[ac + 4] | file[ac + 5] << 8 | file[ac + 6] << 16 | (size_t)file[ac + 7] << 24);
+	}
+	return pos;
+}
+
+/* the frame loop of AGMV_DecodeAGMV / AGMV_DecodeVideo on a file image: `pos` = first byte behind the header.
+   The LZ stage of a batch runs on the pool, one frame per task.  Where frame k+1's chunk is depends on how many payload
+   bytes the bit reader of frame k consumed (it runs past csize into the guard, src/agmv_decode.c:171-198), so the chunks of
+   a batch are first located as if every reader stopped right behind its payload, and after the frames have been
+   decompressed the true positions are checked in order: at the first chunk that was not where it was assumed the batch
+   is cut and the next one starts from the true position.  The bytes behind bpos that the block parser may read on an
+   over-run are those of the reference's ONE persistent buffer: they are taken from `persist` in frame order, which then
+   receives the frame. */
 int agmv_decode_stream(agmv_hip_ctx* ctx, const u8* file, size_t len, size_t pos, uint32_t w, uint32_t h, uint32_t nframes, int ver,
                        int has_audio, unsigned cap_frames, unsigned threads, unsigned long* export_count)
 {
@@ -723,20 +756,38 @@ int agmv_decode_stream(agmv_hip_ctx* ctx, const u8* file, size_t len, size_t pos
 		while (b->filled && !d.failed) pthread_cond_wait(&d.cv, &d.mu);      /* the slot's frames of batch id - nslots are all exported */
 		pthread_mutex_unlock(&d.mu);
 		if (d.failed) break;
-		while (n < d.cap && done + n < nframes) {
-			size_t c = scan_fourcc(file, len, pos, "AGFC"), used = 0;
-			uint32_t usize, csize;
-			if (c + 16 > len) break;
-			usize = file[c + 8] | file[c + 9] << 8 | file[c + 10] << 16 | (uint32_t)file[c + 11] << 24;
-			csize = file[c + 12] | file[c + 13] << 8 | file[c + 14] << 16 | (uint32_t)file[c + 15] << 24;
-			b->h_bpos[n] = agmv_lz_decode_mem(ver, file + c + 16, len - (c + 16), usize, csize, persist, cap, &used);
-			memcpy(b->h_slab + (size_t)n * d.stride, persist, (size_t)b->h_bpos[n] + 16 < d.stride ? (size_t)b->h_bpos[n] + 16 : d.stride);
-			pos = c + 16 + used;
-			if (has_audio) {                               /* AGMV_FindNextAudioChunk + skip (audio is out of scope) */
-				size_t ac = scan_fourcc(file, len, pos, "AGAC");
-				if (ac + 8 <= len) pos = ac + 8 + (file[ac + 4] | file[ac + 5] << 8 | file[ac + 6] << 16 | (size_t)file[ac + 7] << 24);
+		{
+			unlz* jobs = (unlz*)calloc(d.cap, sizeof(unlz));
+			unsigned left, k;
+			size_t spos = pos;
+			if (!jobs) { rc = MEMORY_CORRUPTION_ERR; break; }
+			while (n < d.cap && done + n < nframes) {          /* locate: every reader assumed to stop right behind its payload */
+				size_t c = scan_fourcc(file, len, spos, "AGFC");
+				unlz* j = &jobs[n];
+				if (c + 16 > len) break;
+				j->d = &d; j->ver = ver; j->chunk = c; j->left = &left;
+				j->usize = file[c + 8] | file[c + 9] << 8 | file[c + 10] << 16 | (uint32_t)file[c + 11] << 24;
+				j->csize = file[c + 12] | file[c + 13] << 8 | file[c + 14] << 16 | (uint32_t)file[c + 15] << 24;
+				j->payload = file + c + 16; j->avail = len - (c + 16); j->cap = cap;
+				j->row = b->h_slab + (size_t)n * d.stride;
+				spos = behind_chunk(file, len, c, j->csize < j->avail ? j->csize : j->avail, has_audio);
+				n++;
 			}
-			n++;
+			left = n;
+			for (k = 0; k < n; k++) agmv_pool_submit(d.pool, unlz_task, &jobs[k]);
+			pthread_mutex_lock(&d.mu);
+			while (left) pthread_cond_wait(&d.cv, &d.mu);
+			pthread_mutex_unlock(&d.mu);
+			for (k = 0; k < n; k++) {                          /* in order: stale bytes, persistent buffer, true position of the next chunk */
+				unlz* j = &jobs[k];
+				const size_t bp = j->bpos, tail = bp + 16 < d.stride ? 16 : (bp < d.stride ? d.stride - bp : 0);
+				if (tail) memcpy(j->row + bp, persist + bp, tail);
+				memcpy(persist, j->row, bp < cap ? bp : cap);
+				b->h_bpos[k] = j->bpos;
+				pos = behind_chunk(file, len, j->chunk, j->used, has_audio);
+				if (k + 1 < n && scan_fourcc(file, len, pos, "AGFC") != jobs[k + 1].chunk) { n = k + 1; break; }   /* the rest was decompressed from the wrong place */
+			}
+			free(jobs);
 		}
 		if (!n) break;
 		b->n = n; b->first = done; b->name0 = *export_count + 1;

@@ -126,6 +126,45 @@ def test_decode_reference_sample_file_via_c_api(golden, golden_dir, tmp_path):
         assert hashlib.sha256(pix.astype(np.uint32).tobytes()).hexdigest() == g["pix_sha"][k - 1], k
 
 
+def test_decode_batches_cut_where_a_chunk_is_not_where_it_was_assumed(golden_dir, tmp_path):
+    """The decode driver decompresses the frames of a batch in parallel after locating their chunks as if every bit reader
+    stopped right behind its payload, and cuts the batch at the first chunk that was not there.  Files that defeat the
+    assumption: the reference's splash file with the csize field of some chunks raised past the next chunk's header (the
+    reader stops when usize bytes are out, src/agmv_decode.c:171-198, so the frames are the same).  Decoding with batches of
+    8 frames must give the BMPs of decoding frame by frame (batches of one frame locate nothing ahead)."""
+    data = bytearray(open(os.path.join(golden_dir, "agmv_splash.agmv"), "rb").read())
+    chunks = []
+    pos = 0
+    while True:
+        c = data.find(b"AGFC", pos)
+        if c < 0:
+            break
+        chunks.append(c)
+        pos = c + 16 + int.from_bytes(data[c + 12:c + 16], "little")
+    assert len(chunks) == 119
+    for k in (3, 4, 17, 40, 41, 42, 100):                      # csize now reaches into the chunk after the next one
+        c, nxt = chunks[k], chunks[k + 2]
+        data[c + 12:c + 16] = (nxt + 40 - (c + 16)).to_bytes(4, "little")
+    open(tmp_path / "patched.agmv", "wb").write(bytes(data))
+    H.lib()
+    sums = []
+    for batch in (1, 8):
+        d = tmp_path / ("b%d" % batch)
+        d.mkdir()
+        code = ("import ctypes as C,sys; L=C.CDLL(%r); L.AGMV_DecodeAGMV.argtypes=[C.c_char_p,C.c_ubyte,C.c_int]; "
+                "L.AGMV_SetBatchFrames.argtypes=[C.c_uint]; L.AGMV_SetBatchFrames(%d); sys.exit(L.AGMV_DecodeAGMV(%r,1,1))"
+                % (H.SO, batch, str(tmp_path / "patched.agmv").encode()))
+        r = subprocess.run([sys.executable, "-c", code], cwd=str(d), stderr=subprocess.PIPE, timeout=300)
+        assert r.returncode == 0, r.stderr.decode()[-2000:]
+        h = hashlib.sha256()
+        names = sorted(f for f in os.listdir(d) if f.startswith("quick_export_"))
+        for f in names:                                        # (a reader that runs on past its payload may swallow the next chunk)
+            h.update(f.encode())
+            h.update(open(d / f, "rb").read())
+        sums.append((len(names), h.hexdigest()))
+    assert sums[0][0] >= 100 and sums[0] == sums[1]
+
+
 def test_c_example_runs(tmp_path):
     """examples/encode_decode.c (the reference's README flow) end to end on the GPU"""
     exe = str(tmp_path / "agmv_example")
