@@ -1359,16 +1359,24 @@ __device__ __forceinline__ void fp_walk_region(const FpArgs& A, uint32_t* s_b, u
 	const long cb = sb + (long)lane * FC;                      // first byte of the piece
 	unsigned long long F, C, L, E = 0;
 	{
-		auto nib = [](uint32_t z) -> uint32_t { return ((z >> 7) | (z >> 14) | (z >> 21) | (z >> 28)) & 0xFu; };   // bit 7 of each byte -> 4 bits
-		auto zero7 = [](uint32_t v) -> uint32_t { return ~(((v & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | v) & 0x80808080u; };   // bit 7 of every byte that is 0 (exact)
+		// bit 7 of every byte that is 0 (exact per byte)
+		auto zero7 = [](uint32_t v) -> uint32_t { return ~(((v & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | v) & 0x80808080u; };
+		// the four bits (bit 7 of each byte) of two dwords as one byte: a dot product of the bytes {0, 0x80} with the weights
+		// 1, 2, 4, 8 / 16, 32, 64, 128 is 128 x that byte (v_dot4_u32_u8: two instructions where shifts and ors take a dozen)
+		auto pair8 = [](uint32_t z0, uint32_t z1) -> uint32_t {
+			return __builtin_amdgcn_udot4(z1, 0x80402010u, __builtin_amdgcn_udot4(z0, 0x08040201u, 0u, false), false) >> 7;
+		};
 		uint32_t f2[2] = {0, 0}, c2[2] = {0, 0}, l2[2] = {0, 0}, e2[2] = {0, 0};
 #pragma unroll
-		for (int j = 0; j < 16; j++) {
-			const uint32_t w = s_b[lane * FROW + j];
-			const uint32_t nl = nib(zero7(w ^ 0x4E4E4E4Eu)), nc = nib(zero7(w ^ 0x5E5E5E5Eu)), nn = nib(zero7(w ^ 0x2F2F2F2Fu));
-			l2[j >> 3] |= nl << (4 * (j & 7)); c2[j >> 3] |= nc << (4 * (j & 7));
-			f2[j >> 3] |= (nl | nc | nn) << (4 * (j & 7));
-			if (M512) e2[j >> 3] |= nib(((w & 0x7F7F7F7Fu) + 0x01010101u) & 0x80808080u) << (4 * (j & 7));   // (byte & 0x7f) == 127
+		for (int j = 0; j < 16; j += 2) {
+			const uint32_t w0 = s_b[lane * FROW + j], w1 = s_b[lane * FROW + j + 1];
+			const uint32_t zl0 = zero7(w0 ^ 0x4E4E4E4Eu), zc0 = zero7(w0 ^ 0x5E5E5E5Eu), zn0 = zero7(w0 ^ 0x2F2F2F2Fu);
+			const uint32_t zl1 = zero7(w1 ^ 0x4E4E4E4Eu), zc1 = zero7(w1 ^ 0x5E5E5E5Eu), zn1 = zero7(w1 ^ 0x2F2F2F2Fu);
+			const int h = j >> 3, sh = 4 * (j & 7);
+			l2[h] |= pair8(zl0, zl1) << sh;
+			c2[h] |= pair8(zc0, zc1) << sh;
+			f2[h] |= pair8(zl0 | zc0 | zn0, zl1 | zc1 | zn1) << sh;
+			if (M512) e2[h] |= pair8(((w0 & 0x7F7F7F7Fu) + 0x01010101u) & 0x80808080u, ((w1 & 0x7F7F7F7Fu) + 0x01010101u) & 0x80808080u) << sh;   // (byte & 0x7f) == 127
 		}
 		F = (unsigned long long)f2[1] << 32 | f2[0]; C = (unsigned long long)c2[1] << 32 | c2[0];
 		L = (unsigned long long)l2[1] << 32 | l2[0]; E = (unsigned long long)e2[1] << 32 | e2[0];
