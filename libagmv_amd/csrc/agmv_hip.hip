@@ -1704,7 +1704,7 @@ __device__ __forceinline__ void decode_block_staged(const StagedSrc& src, uint32
 			for (int k = 0; k < 9; k++) {
 				const uint32_t w = *(lds32)(src.lds + a + 4u * k);
 				const uint32_t z = ((w & 0x7f7f7f7fu) + 0x01010101u) & 0x80808080u;     // bit 7 of every byte equal to 127
-				const uint32_t nib = ((z >> 7) | (z >> 14) | (z >> 21) | (z >> 28)) & 0xFu;
+				const uint32_t nib = __builtin_amdgcn_udot4(z, 0x08040201u, 0u, false) >> 7;    // those four bits, adjacent (bytes {0, 0x80} . weights 1, 2, 4, 8)
 				em |= (unsigned long long)nib << (4 * k);
 			}
 			m = (uint32_t)(em >> (d1 & 3u));
