@@ -43,6 +43,9 @@ def parse_args():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="c3", choices=["c3", "c2", "c5"])
+    ap.add_argument("--normal-heavy", action="store_true",
+                    help="also time k_encode on a NORMAL-heavy variant of the clip (reported as roofline_normal_heavy; off by default so "
+                         "that a profile of the default command holds the headline launches only)")
     ap.add_argument("--frames", type=int, default=0, help="frames per GPU (default: the workload's)")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="weak: every rank its own clip of --frames frames; strong: ONE clip of --frames frames split over the ranks by GOP range")
@@ -282,7 +285,7 @@ def main():
             gpu_bits = [out[f, :int(usz[f])].cpu().numpy() for f in range(n_cpu)]
             gpu_pix = [dec[f].cpu().numpy().view(np.uint32).reshape(-1) for f in range(n_cpu)]
             res["cpu_baseline"] = cpu_baseline(wl, p0, p1, list(f_np), gpu_bits, gpu_pix)
-        if world == 1 and npx > 500000 and args.scaling == "weak":     # (last: it re-uses the bitstream slab)
+        if args.normal_heavy and world == 1 and npx > 500000 and args.scaling == "weak":     # (last: it re-uses the bitstream slab)
             res["roofline_normal_heavy"] = normal_heavy_leg(torch, hip, frames, W, H, first_fc, out, sizes)
         print(json.dumps(res))
     if dist is not None:
