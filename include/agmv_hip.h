@@ -108,6 +108,8 @@ int agmv_hip_within2_count(agmv_hip_ctx* ctx, const uint32_t a[16], const uint32
  *  - the encode entry points of ONE context share its look-back status and control words: a second encode is
  *    ordered behind the first (on another stream it waits for it through an event); use one context per
  *    concurrent encoder;
+ *  - likewise the parse / decode entry points of ONE context share its parser work areas and repair bitmap: calls on
+ *    different streams of one context must not overlap; use one context per concurrent decoder;
  *  - a device-side wait that runs into its bound (never observed on a healthy GPU) makes agmv_hip_check fail AND
  *    overwrites every size of that batch with 0xFFFFFFFF, so the bytes cannot be taken for valid ones. */
 
