@@ -1559,8 +1559,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
 }
 
 // entry bitmaps -> offsets[]: the region's entries are listed in LDS (byte position inside the region, in order) and go
-// out as coalesced rows.  Listing: sparse bitmaps -- every lane walks the set bits of its own piece; dense ones (runs of
-// COPY: 64 entries in a piece) -- piece by piece, the lanes whose bit is set write at the rank of their bit.
+// out as coalesced rows.
 __global__ __launch_bounds__(64) void k_fp_expand(FpArgs A)
 {
 	__shared__ uint16_t s_pos[FRB];
@@ -1585,25 +1584,29 @@ __global__ __launch_bounds__(64) void k_fp_expand(FpArgs A)
 			V_n = lane < FOWN ? A.vm[((size_t)f * A.maxR + r + gridDim.x) * FOWN + lane] : 0ull;
 		}
 		if (kb >= A.nblk) break;                                // (uniform) blocks beyond the frame are never entered
-		const uint32_t n = (uint32_t)__popcll(V);
+		const uint32_t vlo = (uint32_t)V, vhi = (uint32_t)(V >> 32);
+		const uint32_t n = (uint32_t)__popc(vlo) + (uint32_t)__popc(vhi);
 		const uint32_t incl = wave_incl_scan(n, lane);
 		const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-		if (__ballot(n > 40u) == 0) {
-			uint32_t j = incl - n;
-			while (V) {
-				s_pos[j++] = (uint16_t)(lane * FC + ctz64(V));
-				V &= V - 1ull;
-			}
-		} else {
-			const uint32_t vlo = (uint32_t)V, vhi = (uint32_t)(V >> 32);
-			uint32_t j = 0;
-#pragma unroll 4
-			for (int c = 0; c < FOWN; c++) {
-				const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)vlo, c), hi = (uint32_t)__builtin_amdgcn_readlane((int)vhi, c);
-				const unsigned long long Vc = (unsigned long long)hi << 32 | lo;
-				if ((Vc >> lane) & 1ull) s_pos[j + __builtin_amdgcn_mbcnt_hi(hi, __builtin_amdgcn_mbcnt_lo(lo, 0u))] = (uint16_t)(c * FC + lane);
-				j += (uint32_t)__popcll(Vc);
-			}
+		const uint32_t first = incl - n;
+		// pieces with few entries: every lane walks the set bits of its own (32 bits at a time: one-instruction bit scans);
+		// dense pieces (a run of COPYs: up to 64 entries) one by one by the whole wave, each lane whose bit is set writing at
+		// the rank of its bit
+		unsigned long long dense = __ballot(n >= 32u);
+		if (n < 32u) {
+			uint32_t j = first, m = vlo;
+			const uint32_t base = (uint32_t)lane * FC;
+			while (m) { s_pos[j++] = (uint16_t)(base + (uint32_t)__builtin_ctz(m)); m &= m - 1u; }
+			m = vhi;
+			while (m) { s_pos[j++] = (uint16_t)(base + 32u + (uint32_t)__builtin_ctz(m)); m &= m - 1u; }
+		}
+		while (dense) {                                        // (uniform)
+			const int c = (int)ctz64(dense);
+			dense &= dense - 1ull;
+			const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)vlo, c), hi = (uint32_t)__builtin_amdgcn_readlane((int)vhi, c);
+			const uint32_t at = (uint32_t)__builtin_amdgcn_readlane((int)first, c);
+			if ((((unsigned long long)hi << 32 | lo) >> lane) & 1ull)
+				s_pos[at + __builtin_amdgcn_mbcnt_hi(hi, __builtin_amdgcn_mbcnt_lo(lo, 0u))] = (uint16_t)(c * FC + lane);
 		}
 		wave_lds_sync();
 		for (uint32_t i = lane; i < tot; i += 64)
