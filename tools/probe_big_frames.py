@@ -1,5 +1,7 @@
+# both parser forms on large and odd geometries (4K, 8K, one block, one block row, one block column), both colour modes
 import sys, os, torch, numpy as np
-sys.path.insert(0, '..'); sys.path.insert(0, '/root/repo/tests')
+R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, 'tests'))
 import synth as S
 from libagmv_amd import AgmvHip
 hip = AgmvHip(0)
