@@ -547,6 +547,27 @@ def test_parser_proof_repair_and_fallback(torch, hip, monkeypatch, mode512):
     assert torch.equal(dec_a, dec_b) and torch.equal(o_b, o_par) and torch.equal(n_b, n_par)
 
 
+@pytest.mark.parametrize("geom", [(3840, 2160, 4), (4, 4, 9), (2052, 4, 5), (8, 1024, 6)])
+@pytest.mark.parametrize("mode512", [True, False])
+def test_parser_forms_agree_on_large_and_degenerate_frames(torch, hip, monkeypatch, geom, mode512):
+    """speculative walks + proof against the map / stitch / emit kernels on a 4K frame (1 100 regions of 59 pieces per
+    frame), one block, one block row and one block column: same entry offsets, every block entered, nothing given up"""
+    W, H, T = geom
+    p0, p1 = S.content_palettes([S.synth_frame(min(W, 640), min(H, 480), 0)])
+    hip.set_palette(p0, p1, mode512)
+    out, sizes = hip.encode_dev(hip.synth_dev(W, H, 0, T), T, W, H)
+    hip.check()
+    monkeypatch.delenv("AGMV_HIP_PARSE", raising=False)
+    o1, n1 = hip.parse_dev(out, sizes, T, W, H)
+    assert hip.parse_fallback_frames() == 0
+    monkeypatch.setenv("AGMV_HIP_PARSE", "robust")
+    o2, n2 = hip.parse_dev(out, sizes, T, W, H)
+    torch.cuda.synchronize()
+    nblk = W * H // 16
+    assert n1.cpu().tolist() == [nblk] * T and torch.equal(n1, n2)
+    assert torch.equal(o1, o2)
+
+
 @pytest.mark.parametrize("first_fc", [0, 2])
 def test_parse_decode_in_ranges(torch, hip, monkeypatch, first_fc):
     """agmv_hip_parse_decode_frames_dev cut into ranges of GOPs (parser on its own stream, reconstruction of a range behind
