@@ -181,14 +181,12 @@ def main():
     out = torch.empty((n_enc, stride), dtype=torch.uint8, device=dev)
     sizes = torch.empty(n_enc, dtype=torch.int32, device=dev)
     nblk = npx // 16
-    offs = torch.empty((n_enc, nblk), dtype=torch.int32, device=dev)
     nent = torch.empty(n_enc, dtype=torch.int32, device=dev)
     dec = torch.empty((n_enc, H, W), dtype=torch.int32, device=dev)
 
     def step():
         hip.encode_dev(frames, n_enc, W, H, first_fc, out=out, sizes=sizes)
-        hip.parse_dev(out, sizes, n_enc, W, H, offsets=offs, nentered=nent)
-        hip.decode_dev(out, sizes, offs, nent, n_enc, W, H, first_fc, out=dec)
+        hip.decode_bitstreams_dev(out, sizes, n_enc, W, H, first_fc, out=dec, nentered=nent)   # parser + k_decode, entry bitmaps in between
 
     def barrier():
         torch.cuda.synchronize()

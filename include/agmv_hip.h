@@ -153,7 +153,17 @@ int agmv_hip_parse_decode_frames_dev(agmv_hip_ctx* ctx, const uint8_t* d_bits, s
                                      uint32_t first_frame_count, uint32_t* d_offsets, uint32_t* d_nentered,
                                      uint32_t* d_pix_out, const uint32_t* d_prev_frame,
                                      const uint32_t* d_prev_iframe, void* stream);
-/* After agmv_hip_decode_frames_dev / agmv_hip_parse_decode_frames_dev: 1 when a pixel of that batch derives from d_prev_frame / d_prev_iframe (a block the
+/* The same result without offsets[]: the parser's block-entry bitmaps (one bit per byte of stream) go straight to the
+   reconstruction kernel, which ranks its own blocks in them; frames the speculative parser cannot prove get their bits from
+   the robust kernels.  This is the form the sequence drivers and bench.py use: it saves the 4 bytes per block that
+   agmv_hip_parse_frames_dev writes and agmv_hip_decode_frames_dev reads back (reference: the block loop of
+   AGMV_DecodeFrameChunk, src/agmv_decode.c:224-407, has no such table either -- it walks).  d_nentered may be NULL.
+   Any number of frames (more than 65532 are cut at GOP boundaries internally). */
+int agmv_hip_decode_bitstreams_dev(agmv_hip_ctx* ctx, const uint8_t* d_bits, size_t bits_stride,
+                                   const uint32_t* d_bpos, uint32_t n_frames, uint32_t w, uint32_t h,
+                                   uint32_t first_frame_count, uint32_t* d_nentered, uint32_t* d_pix_out,
+                                   const uint32_t* d_prev_frame, const uint32_t* d_prev_iframe, void* stream);
+/* After agmv_hip_decode_frames_dev / agmv_hip_parse_decode_frames_dev / agmv_hip_decode_bitstreams_dev: 1 when a pixel of that batch derives from d_prev_frame / d_prev_iframe (a block the
    bitstream did not rewrite before it was read: stale tail after `escape`, COPY in the first GOP, a FILL / NORMAL block cut
    off by bpos -- reference src/agmv_decode.c:229-232, :268-271, :277-285, :310-314), 0 when the batch is a function of its
    own bitstreams alone, negative on error.  What a GOP-sharded decode needs to know before it trusts a range decoded from
@@ -179,7 +189,7 @@ int agmv_hip_histogram_dev(agmv_hip_ctx* ctx, const uint32_t* d_pix, size_t n_pi
 
 /* optional timing: when enabled the library records HIP events on the caller's stream around its three kernel
    groups; agmv_hip_last_kernel_ms(which) returns the last launch's duration in ms (0 = k_encode, 1 = the parser
-   kernels, 2 = k_decode + k_fixup, 3 = the whole of agmv_hip_parse_decode_frames_dev), or a negative value if
+   kernels, 2 = k_decode + k_fixup, 3 = the whole of agmv_hip_parse_decode_frames_dev / agmv_hip_decode_bitstreams_dev), or a negative value if
    unavailable */
 int   agmv_hip_enable_timing(agmv_hip_ctx* ctx, int on);
 float agmv_hip_last_kernel_ms(agmv_hip_ctx* ctx, int which);

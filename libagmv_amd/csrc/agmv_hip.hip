@@ -132,6 +132,12 @@ struct agmv_hip_ctx {
 	size_t fp_ws_cap;               // in bytes
 	uint32_t* d_fp_fstate;          // frame states of the last parse (inside d_fp_ws) and how many
 	uint32_t fp_frames;
+	unsigned long long* fp_vm;      // bitmap form of the last parse (inside d_fp_ws): entry bitmaps, first block per region, tile entries
+	uint32_t* fp_kb;
+	uint32_t* fp_tidx;
+	uint32_t fp_maxR;
+	uint32_t* d_nent_own;           // agmv_hip_decode_bitstreams_dev without a caller's nentered[]
+	size_t nent_cap;
 	hipEvent_t ev_enc;              // end of the last encode launch (encodes of one context share status / control words)
 	hipStream_t enc_stream;         // ... and the stream it went to
 	int have_enc;
@@ -992,6 +998,12 @@ constexpr uint32_t J_EXIT = 0x8000u;    // jump leaves the chunk: J_EXIT | offse
 constexpr uint32_t J_END = 0xFFFFu;     // chain left the readable stream (position > bpos)
 constexpr uint32_t X_END = 63u;         // chunk map: exit code of an ended chain
 
+// geometry of the fast parser (k_fp_*, below); the robust kernels can deliver their result in its bitmap form
+constexpr int FC = 64;                  // bytes per piece (one lane)
+constexpr int FH = 4;                   // run-in pieces
+constexpr int FOWN = 64 - FH - 1;       // pieces a region owns (lane 63 holds the piece behind it)
+constexpr int FRB = FOWN * FC;          // bytes a region owns
+
 struct ParseArgs {
 	const uint8_t* bits;
 	unsigned long long stride;
@@ -1003,6 +1015,8 @@ struct ParseArgs {
 	uint32_t* nentered;
 	uint32_t n_frames, nblk;
 	const uint32_t* fstate; // != NULL: only the frames the fast path gave up on (fstate[f] == FS_BAD) are parsed here
+	unsigned long long* vm; // != NULL: the result goes out as entry BITS (the fast parser's bitmaps, [frame][maxR * FOWN] words of 64 bytes of stream) instead of offsets[]
+	uint32_t maxR;
 };
 constexpr uint32_t FS_OK = 0, FS_TODO = 1, FS_BAD = 2;
 
@@ -1138,6 +1152,7 @@ __global__ __launch_bounds__(64) void k_parse_chunks(ParseArgs A)
 #pragma unroll
 		for (int q = 0; q < PCD; q++) raw[q] = nxt[q];
 		if (c + gridDim.x < nch) load_chunk(nxt, fbits, (uint32_t)A.stride, (c + gridDim.x) * PC, lane);   // in flight over this chunk
+		if (A.vm && lane < PC / 64) A.vm[(size_t)f * A.maxR * FOWN + c * (PC / 64) + lane] = 0ull;   // k_parse_emit ORs the entry bits in (a later launch); FOWN words per region, linear in the byte position
 		const uint32_t mtot = parse_chunk_nodes<M512>(S, /*rank_at*/ nn[1], /*npos*/ S.jl[1], nullptr, nn[0], raw, bpos, cs, lane);
 		const uint32_t k0 = lane < 33 ? nn[1][lane] : 0u;         // first node at or after entry offset `lane` (rank_at dies below)
 		wave_lds_sync();
@@ -1233,7 +1248,10 @@ __global__ __launch_bounds__(64) void k_parse_emit(ParseArgs A)
 			ce_n = A.centry[g0 + c + gridDim.x];
 			load_chunk(nxt, fbits, (uint32_t)A.stride, (c + gridDim.x) * PC, lane);
 		}
-		if (c == 0 && lane == 0) off[0] = 0;                   // block 0 is entered at byte 0
+		unsigned long long* fvm = A.vm ? A.vm + (size_t)f * A.maxR * FOWN : nullptr;
+		if (c == 0 && lane == 0) {                             // block 0 is entered at byte 0
+			if (fvm) atomicOr(fvm, 1ull); else off[0] = 0;
+		}
 		if (o == 0xFFu) continue;                              // the chain ended before this chunk (uniform)
 		if (kb + 1u >= A.nblk) continue;                       // every block this chunk could enter is beyond the frame
 		const uint32_t cs = c * PC;
@@ -1273,7 +1291,10 @@ __global__ __launch_bounds__(64) void k_parse_emit(ParseArgs A)
 				const bool on = k < mtot && mark[k] && (ev & 0x8000u);
 				const unsigned long long m = __ballot(on);
 				const uint32_t kk = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-				if (on && kk < A.nblk) off[kk] = cs + (ev & 0x7FFFu);
+				if (on && kk < A.nblk) {
+					const uint32_t pos = cs + (ev & 0x7FFFu);
+					if (fvm) atomicOr(fvm + (pos >> 6), 1ull << (pos & 63u)); else off[kk] = pos;
+				}
 				base += (uint32_t)__popcll(m);
 			}
 		}
@@ -1305,10 +1326,6 @@ __global__ __launch_bounds__(64) void k_parse_emit(ParseArgs A)
 // Exit / entry codes: 0..33 = the next block is entered at that byte of the next piece; FX_SLIDE = no new entry, the
 // resync (src/agmv_decode.c:236-243) continues into the next piece; FX_END = the chain ended.
 // ----------------------------------------------------------------------------------------------
-constexpr int FC = 64;                  // bytes per piece (one lane)
-constexpr int FH = 4;                   // run-in pieces
-constexpr int FOWN = 64 - FH - 1;       // pieces a region owns (lane 63 holds the piece behind it)
-constexpr int FRB = FOWN * FC;          // bytes a region owns
 constexpr int FROW = FC / 4 + 1;        // LDS dwords per piece (odd stride: no bank conflicts between the lanes' pieces)
 constexpr uint32_t FX_SLIDE = 64u, FX_END = 65u, FX_UNSET = 66u, FX_MERGE = 128u;
 constexpr int FP_REPAIRS = 24;          // regions of one frame walked again (serially, by the frame's wave) before the frame is given up
@@ -1328,7 +1345,10 @@ struct FpArgs {
 	uint32_t* offsets;
 	uint32_t* nentered;
 	uint32_t n_frames, nblk, maxR;
+	uint32_t* tidx;             // [n_frames][tpfd + 1] byte position at which the first block of every k_decode tile is entered (TIDX_NONE: not entered)
+	uint32_t tpfd;              // k_decode tiles per frame
 };
+constexpr uint32_t TIDX_NONE = 0xFFFFFFFFu;
 
 __device__ __forceinline__ uint32_t ctz64(unsigned long long m) { return (uint32_t)__builtin_ctzll(m); }       // m != 0
 __device__ __forceinline__ unsigned long long above(uint32_t q) { return (~0ull << q) << 1; }     // bits > q (q <= 63)
@@ -1615,6 +1635,96 @@ __global__ __launch_bounds__(64) void k_fp_expand(FpArgs A)
 	}
 }
 
+// position of the k-th set bit (k = 0: the lowest) of v; k < popcount(v)
+__device__ __forceinline__ uint32_t select64(unsigned long long v, uint32_t k)
+{
+	uint32_t w = (uint32_t)v, base = 0, c = (uint32_t)__popc(w);
+	if (k >= c) { k -= c; w = (uint32_t)(v >> 32); base = 32; }
+	c = (uint32_t)__popc(w & 0xFFFFu); if (k >= c) { k -= c; w >>= 16; base += 16; }
+	w &= 0xFFFFu;
+	c = (uint32_t)__popc(w & 0xFFu);   if (k >= c) { k -= c; w >>= 8;  base += 8; }
+	w &= 0xFFu;
+	c = (uint32_t)__popc(w & 0xFu);    if (k >= c) { k -= c; w >>= 4;  base += 4; }
+	w &= 0xFu;
+	c = (uint32_t)__popc(w & 0x3u);    if (k >= c) { k -= c; w >>= 2;  base += 2; }
+	return base + ((k >= (w & 1u)) ? 1u : 0u);
+}
+
+// Entry bitmaps -> where the first block of every k_decode tile (DEC_T consecutive blocks) is entered.  This is all
+// k_decode needs besides the bitmaps themselves: it ranks its own blocks in the bitmap words between two tile entries
+// (offsets[] -- 4 bytes per block written by k_fp_expand and read back -- never exists on this path).
+// One wave per region, like k_fp_expand; tidx is pre-filled with TIDX_NONE.
+__global__ __launch_bounds__(64) void k_fp_tiles(FpArgs A)
+{
+	const int lane = threadIdx.x;
+	const uint32_t f = blockIdx.y;
+	if (A.fstate[f] == FS_BAD) return;                         // (cannot happen behind k_fp_recount; a frame without bitmaps has no tiles)
+	const uint32_t nreg = min(A.bpos[f] / FRB + 1u, A.maxR);
+	uint32_t* tx = A.tidx + (size_t)f * (A.tpfd + 1);
+	for (uint32_t r = blockIdx.x; r < nreg; r += gridDim.x) {
+		const uint32_t kb = A.kb[(size_t)f * A.maxR + r];
+		if (kb >= A.nblk) break;                                // (uniform) blocks beyond the frame are never entered
+		const unsigned long long V = lane < FOWN ? A.vm[((size_t)f * A.maxR + r) * FOWN + lane] : 0ull;
+		const uint32_t n = (uint32_t)__popcll(V);
+		const uint32_t incl = wave_incl_scan(n, lane);
+		const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+		const uint32_t first = incl - n;
+		uint32_t end = kb + tot;
+		if (end > A.nblk) end = A.nblk;
+		for (uint32_t m = (kb + DEC_T - 1) / DEC_T; m * DEC_T < end; m++) {     // (uniform) tiles whose first block is entered in this region
+			const uint32_t target = m * DEC_T - kb;
+			if (target >= first && target < first + n) tx[m] = r * FRB + (uint32_t)lane * FC + select64(V, target - first);
+		}
+	}
+}
+
+// Frames the fast parser gave up on, after the robust kernels have set their entry bits (k_parse_emit, bitmap form): count
+// the entries per region and number the blocks, as k_fp_finish does for a proven frame.
+constexpr uint32_t FS_FIXED = 3;
+__global__ __launch_bounds__(64) void k_fp_recount(FpArgs A)
+{
+	const int lane = threadIdx.x;
+	for (uint32_t f = blockIdx.x; f < A.n_frames; f += gridDim.x) {
+		if (A.fstate[f] != FS_BAD) continue;
+		const uint32_t nreg = min(A.bpos[f] / FRB + 1u, A.maxR);
+		uint32_t run = 0;
+		for (uint32_t r0 = 0; r0 < nreg; r0 += 64) {
+			const uint32_t r = r0 + lane;
+			uint32_t n = 0;
+			if (r < nreg) {
+				const unsigned long long* v = A.vm + ((size_t)f * A.maxR + r) * FOWN;
+				for (int k = 0; k < FOWN; k++) n += (uint32_t)__popcll(v[k]);
+			}
+			const uint32_t incl = wave_incl_scan(n, lane);
+			if (r < nreg) A.kb[(size_t)f * A.maxR + r] = run + incl - n;
+			run += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+		}
+		if (lane == 0) A.fstate[f] = FS_FIXED;
+	}
+}
+
+// entry position of block b of frame f from the bitmaps (b < nentered[f]); the slow, self-contained form: k_fixup and
+// the tiles of k_decode whose entries span more bitmap words than the workgroup has lanes
+__device__ uint32_t bm_offset_of(const unsigned long long* vm, const uint32_t* kb, uint32_t maxR, uint32_t bpos, uint32_t f, uint32_t b)
+{
+	const uint32_t nreg = min(bpos / FRB + 1u, maxR);
+	const uint32_t* kbp = kb + (size_t)f * maxR;
+	uint32_t lo = 0, hi = nreg - 1;
+	while (lo < hi) {                                          // the last region whose first block number is <= b
+		const uint32_t mid = (lo + hi + 1) >> 1;
+		if (kbp[mid] <= b) lo = mid; else hi = mid - 1;
+	}
+	uint32_t rem = b - kbp[lo];
+	const unsigned long long* v = vm + ((size_t)f * maxR + lo) * FOWN;
+	for (int k = 0; k < FOWN; k++) {
+		const unsigned long long w = v[k];
+		const uint32_t c = (uint32_t)__popcll(w);
+		if (rem < c) return lo * FRB + (uint32_t)k * FC + select64(w, rem);
+		rem -= c;
+	}
+	return 0;                                                  // (not reached for b < nentered)
+}
+
 struct DecArgs {
 	const uint8_t* bits;
 	unsigned long long stride;
@@ -1628,6 +1738,11 @@ struct DecArgs {
 	uint32_t* dirty;
 	uint32_t n_frames, w, h, bw, nblk, tpf, first_fc, phase, n_groups;
 	uint32_t grp0;          // first GOP of this launch (the grid covers GOPs grp0 .. grp0 + gridDim.x / tpf - 1)
+	// bitmap form (BM kernels): the parser's entry bitmaps, first block number per region, tile entries -- no offsets[]
+	const unsigned long long* vm;
+	const uint32_t* kb;
+	const uint32_t* tidx;
+	uint32_t maxR;
 };
 
 // one 4x4 block of D2 (512 colours, src/agmv_decode.c:234-319) or D3 (256 colours, :335-396).
@@ -1794,6 +1909,15 @@ __device__ __forceinline__ void store_block(uint32_t* frame, uint32_t poff, uint
 	}
 }
 
+// buffer descriptor from wave-uniform inputs, made PROVABLY uniform (readfirstlane on both pointer halves and the size): otherwise
+// hipcc wraps every buffer op in a waterfall loop
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t uniform_rsrc(const void* p, uint32_t bytes)
+{
+	const uint64_t a = (uint64_t)p;
+	const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)a), hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(a >> 32));
+	return __builtin_amdgcn_make_buffer_rsrc((void*)((uint64_t)hi << 32 | lo), 0, __builtin_amdgcn_readfirstlane((int)bytes), 0x00020000);
+}
+
 // K3: one lane = one 4x4 block carried through the <=4 frames of its GOP (img_data and
 // iframe->img_data of the block live in registers).  A block whose value depends on a frame
 // outside the GOP (not rewritten since the GOP started) is flagged in `dirty` and repaired by
@@ -1809,7 +1933,7 @@ __device__ __forceinline__ void store_block(uint32_t* frame, uint32_t poff, uint
 #ifndef DEC_WPE
 #define DEC_WPE 5         // waves per SIMD: 87 VGPRs, no spills; 6 spills and is slower
 #endif
-template <bool M512>
+template <bool M512, bool BM>
 __global__ __launch_bounds__(DEC_T, DEC_WPE) void k_decode(DecArgs A)
 {
 	__shared__ uint32_t s_pal[512];
@@ -1835,68 +1959,59 @@ __global__ __launch_bounds__(DEC_T, DEC_WPE) void k_decode(DecArgs A)
 	const bool has_last = (tile == A.tpf - 1);                 // this workgroup holds block nblk-1
 	const bool is_last = valid && blk == A.nblk - 1;
 
-	// ---- round trip 1: entry offsets, nentered, bpos of every frame of the GOP; previous state of the block
 	uint32_t off[4], ne[4], bp[4];
-#pragma unroll
-	for (int i = 0; i < 4; i++) {
-		const int fi = i < nf ? f_lo + i : f_hi - 1;
-		off[i] = A.offsets[(size_t)fi * A.nblk + b];            // (non-temporal here and in k_fp_expand's stores: 0.375 -> 0.39-0.41 ms, not kept)
-		ne[i] = A.nentered[fi]; bp[i] = A.bpos[fi];
-	}
+	uint32_t r_lo[4], r_len[4];
 	uint32_t cur[16], icol[16];
 	bool stale, istale;
 	// stale / istale: the block's img_data / iframe->img_data still derive from the state before this GOP.  For the first
 	// GOP of the batch that state is the caller's (prev / prev_iframe) and the pixels are right as they are; what the
 	// flags then tell is whether the batch DEPENDS on the state handed in (reported through agmv_hip_decode_prior_dependent).
-	if (group == 0) {                                          // state of the decoder before the batch
-		if (A.prev) load_block(A.prev, poff, A.w, cur);
-		else {
+	auto load_prior = [&]() {
+		if (group == 0) {                                      // state of the decoder before the batch
+			if (A.prev) load_block(A.prev, poff, A.w, cur);
+			else {
 #pragma unroll
-			for (int k = 0; k < 16; k++) cur[k] = 0;
+				for (int k = 0; k < 16; k++) cur[k] = 0;
+			}
+			if (A.prev_iframe) load_block(A.prev_iframe, poff, A.w, icol);
+			else {
+#pragma unroll
+				for (int k = 0; k < 16; k++) icol[k] = 0;
+			}
+		} else {
+#pragma unroll
+			for (int k = 0; k < 16; k++) { cur[k] = 0; icol[k] = 0; }
 		}
-		if (A.prev_iframe) load_block(A.prev_iframe, poff, A.w, icol);
-		else {
-#pragma unroll
-			for (int k = 0; k < 16; k++) icol[k] = 0;
-		}
-	} else {
-#pragma unroll
-		for (int k = 0; k < 16; k++) { cur[k] = 0; icol[k] = 0; }
-	}
-	stale = true; istale = true;
-	// the range the tile's entered blocks can touch in frame i: [first entry, last entry + 33 + 8]; entry offsets
-	// increase with the block index, so it is [offset of lane 0, offset of the last entered lane]
-#pragma unroll
-	for (int i = 0; i < 4; i++) {
-		if (i < nf && valid && blk < ne[i]) {
-			if (tid == 0) s_rng[i][0] = off[i];
-			if (blk + 1 == ne[i] || tid == DEC_T - 1 || blk + 1 == A.nblk) s_rng[i][1] = off[i];   // exactly one lane
-		}
-	}
-	__syncthreads();                                           // ranges (and the palette) visible
-	// ---- round trip 2: the four byte windows, all in flight together
-	uint32_t r_lo[4], r_len[4];
-#pragma unroll
-	for (int i = 0; i < 4; i++) {
-		r_lo[i] = 0; r_len[i] = 0;
-		if (i < nf && tile * DEC_T < ne[i]) {                  // uniform: at least the first block of the tile is entered
-			r_lo[i] = s_rng[i][0] & ~3u;
-			uint32_t len = s_rng[i][1] + 48u - r_lo[i];
-			if (len > (uint32_t)DEC_STAGE) len = DEC_STAGE;
-			r_len[i] = len & ~3u;
-		}
-	}
-	{
-		uint32_t st[4][DEC_SR];
+		stale = true; istale = true;
+	};
+	uint32_t st[4][DEC_SR];                                    // the byte windows on their way from global memory to LDS
+	// The first DEC_T dwords of every window go out as unconditional buffer loads (a lane beyond the window is out of range: 0,
+	// no fetch, NO BRANCH), LAST; the rest -- needed only where a tile's blocks average more than 4 bytes -- under uniform
+	// branches ahead of them.  The compiler waits for an earlier load with the count of loads that follow it on EVERY path,
+	// i.e. those four: the bitmap words are then awaited with the windows still in flight.  (With all of them under branches it
+	// has to assume none was issued, and the first wait drains everything.)
+	auto load_windows = [&]() {
+		__amdgpu_buffer_rsrc_t rs[4];
 #pragma unroll
 		for (int i = 0; i < 4; i++) {
-			const uint8_t* fb = A.bits + (size_t)(i < nf ? f_lo + i : f_lo) * A.stride;
+			const uint8_t* fb = A.bits + (size_t)(i < nf ? f_lo + i : f_lo) * A.stride + r_lo[i];
+			uint32_t nrec = r_lo[i] < (uint32_t)A.stride ? (uint32_t)A.stride - r_lo[i] : 0u;
+			if (nrec > r_len[i]) nrec = r_len[i];
+			rs[i] = uniform_rsrc(fb, nrec & ~3u);
+		}
 #pragma unroll
-			for (int k = 0; k < DEC_SR; k++) {
-				const uint32_t j = (uint32_t)(k * DEC_T + tid) * 4u, pos = r_lo[i] + j;
-				st[i][k] = (j < r_len[i] && pos + 4u <= (uint32_t)A.stride) ? *(const uint32_t*)(fb + pos) : 0u;
+		for (int i = 0; i < 4; i++) {
+#pragma unroll
+			for (int k = 1; k < DEC_SR; k++) {
+				st[i][k] = 0;
+				if ((uint32_t)(k * DEC_T) * 4u < r_len[i])         // (uniform)
+					st[i][k] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rs[i], (uint32_t)(k * DEC_T + tid) * 4u, 0, 0);
 			}
 		}
+#pragma unroll
+		for (int i = 0; i < 4; i++) st[i][0] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rs[i], (uint32_t)tid * 4u, 0, 0);
+	};
+	auto store_windows = [&]() {
 #pragma unroll
 		for (int i = 0; i < 4; i++) {
 #pragma unroll
@@ -1905,7 +2020,145 @@ __global__ __launch_bounds__(DEC_T, DEC_WPE) void k_decode(DecArgs A)
 				if (j < r_len[i]) *(uint32_t*)(s_bytes[i] + j) = st[i][k];
 			}
 		}
+	};
+	if (!BM) {
+		// ---- round trip 1: entry offsets, nentered, bpos of every frame of the GOP; previous state of the block
+#pragma unroll
+		for (int i = 0; i < 4; i++) {
+			const int fi = i < nf ? f_lo + i : f_hi - 1;
+			off[i] = A.offsets[(size_t)fi * A.nblk + b];            // (non-temporal here and in k_fp_expand's stores: 0.375 -> 0.39-0.41 ms, not kept)
+			ne[i] = A.nentered[fi]; bp[i] = A.bpos[fi];
+		}
+		// the range the tile's entered blocks can touch in frame i: [first entry, last entry + 33 + 8]; entry offsets
+		// increase with the block index, so it is [offset of lane 0, offset of the last entered lane]
+#pragma unroll
+		for (int i = 0; i < 4; i++) {
+			if (i < nf && valid && blk < ne[i]) {
+				if (tid == 0) s_rng[i][0] = off[i];
+				if (blk + 1 == ne[i] || tid == DEC_T - 1 || blk + 1 == A.nblk) s_rng[i][1] = off[i];   // exactly one lane
+			}
+		}
+		__syncthreads();                                       // ranges (and the palette) visible
+		// ---- round trip 2: the four byte windows, all in flight together
+#pragma unroll
+		for (int i = 0; i < 4; i++) {
+			r_lo[i] = 0; r_len[i] = 0;
+			if (i < nf && tile * DEC_T < ne[i]) {              // uniform: at least the first block of the tile is entered
+				r_lo[i] = s_rng[i][0] & ~3u;
+				uint32_t len = s_rng[i][1] + 48u - r_lo[i];
+				if (len > (uint32_t)DEC_STAGE) len = DEC_STAGE;
+				r_len[i] = len & ~3u;
+			}
+		}
+	} else {
+		// ---- bitmap form.  Round trip 1 (uniform, scalar loads): where this tile and the next one are entered in each frame.
+		// Round trip 2, all in flight together: the entry bitmap words between the two (one per lane, 64 bytes of stream
+		// each) and the byte windows.  The lanes then rank their blocks in the bitmap: block j of the tile is entered at
+		// the j-th set bit behind the tile's entry -- an exclusive scan of the words' popcounts through LDS, a binary search
+		// of the lane's rank in it, a bit select.
+		uint32_t t0[4], t1[4], P0[4];
+		bool wide[4];
+		{
+			// one vector load for the sixteen words (lane = kind * 4 + frame), broadcast by v_readlane: as scalar loads they
+			// are sixteen scalar-cache misses, and every tile's are different
+			const int q = tid & 3, kind = (tid >> 2) & 3;
+			const int fq = q < nf ? f_lo + q : f_hi - 1;
+			const uint32_t* hp = kind == 0 ? A.nentered + fq : (kind == 1 ? A.bpos + fq : A.tidx + (size_t)fq * (A.tpf + 1) + tile + (kind == 3 ? 1 : 0));
+			const uint32_t hv = *hp;
+#pragma unroll
+			for (int i = 0; i < 4; i++) {
+				ne[i] = (uint32_t)__builtin_amdgcn_readlane((int)hv, i); bp[i] = (uint32_t)__builtin_amdgcn_readlane((int)hv, 4 + i);
+				t0[i] = (uint32_t)__builtin_amdgcn_readlane((int)hv, 8 + i); t1[i] = (uint32_t)__builtin_amdgcn_readlane((int)hv, 12 + i);
+			}
+		}
+		unsigned long long vw[4];
+		bool usew[4];
+		const unsigned long long* vp[4];
+		uint32_t npmax = 1;                                    // words of the longest range (uniform)
+#pragma unroll
+		for (int i = 0; i < 4; i++) {
+			const int fi = i < nf ? f_lo + i : f_hi - 1;
+			const bool has = i < nf && tile * DEC_T < ne[i] && t0[i] != TIDX_NONE;   // uniform
+			r_lo[i] = 0; r_len[i] = 0; P0[i] = 0; wide[i] = false; off[i] = 0; usew[i] = false;
+			uint32_t pc = 0;
+			if (has) {
+				P0[i] = t0[i] >> 6;
+				const uint32_t last = (t1[i] != TIDX_NONE ? t1[i] - 1u : bp[i]) >> 6;   // last word that can hold an entry of this tile
+				wide[i] = last - P0[i] >= (uint32_t)DEC_T;     // (garbage between blocks: the resync can skip any number of bytes)
+				if (!wide[i] && last - P0[i] + 1u > npmax) npmax = last - P0[i] + 1u;
+				pc = P0[i] + (uint32_t)tid;
+				usew[i] = !wide[i] && pc <= last;
+				r_lo[i] = t0[i] & ~3u;
+				uint32_t hi = (t1[i] != TIDX_NONE ? t1[i] : bp[i] + 1u) + 48u;
+				uint32_t len = hi > r_lo[i] ? hi - r_lo[i] : 0u;
+				if (len > (uint32_t)DEC_STAGE) len = DEC_STAGE;
+				r_len[i] = len & ~3u;
+			}
+			vp[i] = A.vm + (size_t)fi * A.maxR * FOWN + (usew[i] ? pc : 0u);   // always a readable word: the four loads go out back to back, unconditionally
+		}
+#pragma unroll
+		for (int i = 0; i < 4; i++) vw[i] = *vp[i];
+		asm volatile("" ::: "memory");                      // the four bitmap loads stay AHEAD of the windows: the first wait then leaves the windows in flight
+		load_windows();
+#pragma unroll
+		for (int i = 0; i < 4; i++) {
+			vw[i] = usew[i] ? vw[i] : 0ull;
+			if (tid == 0) vw[i] &= ~0ull << (t0[i] & 63u);
+		}
+		// scan + search, with the LDS of the byte windows (not yet written) as scratch: [frame][lane] prefix (u16) | word (u64)
+		uint16_t* s_pre = (uint16_t*)&s_bytes[0][0];               // 4 * DEC_T * 2 bytes
+		unsigned long long* s_w = (unsigned long long*)(&s_bytes[0][0] + 4 * DEC_T * 2);
+		uint32_t* s_wt = s_nb;                                 // [frame][wave] entries per wave
+		static_assert(4 * DEC_T * 10 <= 4 * DEC_STAGE && DEC_T / 64 * 4 <= DEC_T, "scratch fits the stage");
+		uint32_t incl[4], cnt[4];
+		const int lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+		for (int i = 0; i < 4; i++) {
+			cnt[i] = (uint32_t)__popcll(vw[i]);
+			incl[i] = wave_incl_scan(cnt[i], lane);
+			if (lane == 63) s_wt[i * (DEC_T / 64) + wave] = incl[i];
+		}
+		lds_barrier();                                         // wave totals visible (an LDS-only barrier: the byte windows stay in flight under the scan and the search)
+#pragma unroll
+		for (int i = 0; i < 4; i++) {
+			uint32_t base = 0;
+#pragma unroll
+			for (int wv = 0; wv < DEC_T / 64; wv++) base += wv < wave ? s_wt[i * (DEC_T / 64) + wv] : 0u;
+			s_pre[i * DEC_T + tid] = (uint16_t)(base + incl[i] - cnt[i]);
+			s_w[i * DEC_T + tid] = vw[i];
+		}
+		lds_barrier();
+		{
+			// the four frames' searches step together (four independent chains of LDS reads); a lane that is not entered
+			// searches too and its result is not used
+			uint32_t st0 = DEC_T / 2;
+			while (st0 >= npmax && st0 > 1) st0 >>= 1;             // largest power of two below npmax (index 0 needs no test)
+			uint32_t pz[4] = {0, 0, 0, 0};                         // the last word whose prefix is <= the lane's rank
+			// (uniform) as many halvings as the longest of the four word ranges needs: a tile of the benchmark clip spans ~14 words
+			for (uint32_t st = st0; st >= 1; st >>= 1) {
+				uint32_t v[4];
+#pragma unroll
+				for (int i = 0; i < 4; i++) v[i] = s_pre[i * DEC_T + pz[i] + st];
+#pragma unroll
+				for (int i = 0; i < 4; i++) pz[i] += v[i] <= (uint32_t)tid ? st : 0u;
+			}
+#pragma unroll
+			for (int i = 0; i < 4; i++) {
+				const uint32_t pre = s_pre[i * DEC_T + pz[i]];
+				const unsigned long long wv = s_w[i * DEC_T + pz[i]];
+				off[i] = ((P0[i] + pz[i]) << 6) + select64(wv, (uint32_t)tid - pre);
+			}
+#pragma unroll
+			for (int i = 0; i < 4; i++) {
+				const int fi = i < nf ? f_lo + i : f_hi - 1;
+				if (wide[i] && i < nf && valid && blk < ne[i]) off[i] = bm_offset_of(A.vm, A.kb, A.maxR, bp[i], (uint32_t)fi, blk);   // (uniform branch; exotic)
+			}
+		}
+		lds_barrier();                                         // scratch read: the byte windows may land
 	}
+	if (!BM) { load_windows(); store_windows(); }
+	else store_windows();
+	load_prior();                                              // (only the first GOP of a batch reads anything here: kept out of the prologue, whose registers hold the byte windows)
 	__syncthreads();                                           // the last wait on global loads in this kernel
 
 	bool anystale = false, needfix = false;
@@ -1964,7 +2217,7 @@ __global__ __launch_bounds__(DEC_T, DEC_WPE) void k_decode(DecArgs A)
 // 64 bitmap bits are clear exits at once, the others replay ALL frames in order for their flagged positions from the true
 // pre-batch state and overwrite the output.  The wave that holds block nblk-1 also replays block nblk-2 (flagged or not:
 // a replay from the true state writes the true pixels), in the lane below when both sit in one wave, else in lane 1.
-template <bool M512>
+template <bool M512, bool BM>
 __global__ __launch_bounds__(64) void k_fixup(DecArgs A)
 {
 	__shared__ uint32_t s_pal[512];
@@ -2007,8 +2260,8 @@ __global__ __launch_bounds__(64) void k_fixup(DecArgs A)
 		const uint32_t own3 = cur[3];
 		if (active && blk < A.nentered[f]) {
 			ByteSrc src{A.bits + (size_t)f * A.stride, (uint32_t)A.stride};
-			decode_block<M512>(src, A.offsets[(size_t)f * A.nblk + blk], A.bpos[f], s_pal, cur, icol,
-			                   false, stale, fill_written);
+			const uint32_t o = BM ? bm_offset_of(A.vm, A.kb, A.maxR, A.bpos[f], f, blk) : A.offsets[(size_t)f * A.nblk + blk];
+			decode_block<M512>(src, o, A.bpos[f], s_pal, cur, icol, false, stale, fill_written);
 		}
 		const uint32_t left = (uint32_t)__builtin_amdgcn_readlane((int)cur[7], nb_lane < 0 ? 0 : nb_lane);   // img_data[(x-1)+(y+1)*w] of the left neighbour
 		if (is_last && fill_written) {
@@ -2201,7 +2454,7 @@ extern "C" void agmv_hip_destroy(agmv_hip_ctx* c)
 	(void)hipSetDevice(c->device);
 	(void)hipFree(c->d_lut); (void)hipFree(c->d_mtx); (void)hipFree(c->d_pal); (void)hipFree(c->d_ctrl);
 	(void)hipFree(c->d_status); (void)hipFree(c->d_dirty); (void)hipFree(c->d_parse_ws); (void)hipFree(c->d_fp_ws); (void)hipFree(c->d_ient_tmp);
-	(void)hipFree(c->d_nn_pal); (void)hipFree(c->d_nn_pix); (void)hipFree(c->d_nn_ent);
+	(void)hipFree(c->d_nent_own); (void)hipFree(c->d_nn_pal); (void)hipFree(c->d_nn_pix); (void)hipFree(c->d_nn_ent);
 	if (c->ev_enc) (void)hipEventDestroy(c->ev_enc);
 	for (int i = 0; i < 8; i++) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
 	if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
@@ -2485,7 +2738,8 @@ static int check_slab(const uint8_t* d_bits, size_t stride)
 // the robust parser kernels over n_frames frames on stream s (workspace of the context: launches that share it must be
 // ordered); fstate != NULL: only the frames marked FS_BAD
 static int parse_launch_robust(agmv_hip_ctx* c, const uint8_t* d_bits, size_t stride, const uint32_t* d_bpos, uint32_t n_frames,
-                               uint32_t nblk, uint32_t* d_offsets, uint32_t* d_nentered, size_t ws_frames, const uint32_t* fstate, hipStream_t s)
+                               uint32_t nblk, uint32_t* d_offsets, uint32_t* d_nentered, size_t ws_frames, const uint32_t* fstate, hipStream_t s,
+                               unsigned long long* vm = nullptr, uint32_t maxR = 0)
 {
 	const size_t cpf = (stride + PC) / PC, maxchunks = cpf * ws_frames;
 	const size_t need = ws_frames + 1 + maxchunks + (maxchunks * 33 + 1) / 2 + 16;   // dwords: cum | centry | summ (u16)
@@ -2499,8 +2753,10 @@ static int parse_launch_robust(agmv_hip_ctx* c, const uint8_t* d_bits, size_t st
 	memset(&A, 0, sizeof(A));
 	A.bits = d_bits; A.stride = stride; A.bpos = d_bpos; A.offsets = d_offsets; A.nentered = d_nentered;
 	A.cum = c->d_parse_ws; A.centry = A.cum + ws_frames + 1; A.summ = (uint16_t*)(A.centry + maxchunks);
-	A.n_frames = n_frames; A.nblk = nblk; A.fstate = fstate;
-	const dim3 gy(1, n_frames < 65535u ? n_frames : 65535u);
+	A.n_frames = n_frames; A.nblk = nblk; A.fstate = fstate; A.vm = vm; A.maxR = maxR;
+	// the exception path (fstate): a few rows of workgroups stride over the frames and leave those that are not FS_BAD at
+	// once -- with one row per frame the three gated launches cost 0.03 ms per 1024 frames for zero frames to parse
+	const dim3 gy(1, fstate ? (n_frames < 64u ? n_frames : 64u) : (n_frames < 65535u ? n_frames : 65535u));
 	// one wave per workgroup, each striding over the chunks of one frame: ~512 waves per CU in the grid (measured on
 	// 1024 x 1080p: 8 / 16 / 32 / 64 / 128 / 256 per frame -> 2.85 / 2.30 / 1.96 / 1.87 / 1.83 / 1.84 ms)
 	uint32_t gx = (uint32_t)(((size_t)c->n_cu * 512 + n_frames - 1) / n_frames);
@@ -2527,16 +2783,20 @@ static int parse_launch_robust(agmv_hip_ctx* c, const uint8_t* d_bits, size_t st
 // the parser: speculative walks proven per frame (k_fp_*), the robust kernels for the frames that could not be proven.
 // AGMV_HIP_PARSE=robust runs the robust kernels alone.
 static int parse_launch(agmv_hip_ctx* c, const uint8_t* d_bits, size_t stride, const uint32_t* d_bpos, uint32_t n_frames,
-                        uint32_t nblk, uint32_t* d_offsets, uint32_t* d_nentered, size_t ws_frames, hipStream_t s)
+                        uint32_t nblk, uint32_t* d_offsets, uint32_t* d_nentered, size_t ws_frames, hipStream_t s, bool bitmap = false)
 {
 	const char* mode = getenv("AGMV_HIP_PARSE");
+	const bool robust_only = mode && strcmp(mode, "robust") == 0;
 	c->d_fp_fstate = nullptr; c->fp_frames = 0;
-	if (n_frames > 65535u || (mode && strcmp(mode, "robust") == 0))
+	if (!bitmap && (n_frames > 65535u || robust_only))
 		return parse_launch_robust(c, d_bits, stride, d_bpos, n_frames, nblk, d_offsets, d_nentered, ws_frames, nullptr, s);
+	if (n_frames > 65535u) { snprintf(g_err, sizeof(g_err), "agmv_hip: more than 65535 frames in one parser launch"); return -1; }
 	const size_t maxR = (stride + FRB - 1) / FRB + 1;
 	const size_t nreg = maxR * ws_frames;
+	const uint32_t tpfd = (nblk + DEC_T - 1) / DEC_T;
 	const size_t b_rec = nreg * sizeof(uint4), b_vm = nreg * FOWN * 8, b_kb = nreg * 4, b_fs = ((ws_frames * 4 + 15) & ~(size_t)15);
-	const size_t need = b_rec + b_vm + b_kb + b_fs;
+	const size_t b_tx = bitmap ? (((size_t)ws_frames * (tpfd + 1) * 4 + 15) & ~(size_t)15) : 0;
+	const size_t need = b_rec + b_vm + b_kb + b_fs + b_tx;
 	if (need > c->fp_ws_cap) {
 		if (c->d_fp_ws) CK(hipFree(c->d_fp_ws));
 		c->d_fp_ws = nullptr; c->fp_ws_cap = 0;
@@ -2548,6 +2808,7 @@ static int parse_launch(agmv_hip_ctx* c, const uint8_t* d_bits, size_t stride, c
 	A.bits = d_bits; A.stride = stride; A.bpos = d_bpos; A.offsets = d_offsets; A.nentered = d_nentered;
 	uint8_t* w = (uint8_t*)c->d_fp_ws;
 	A.rec = (uint4*)w; A.vm = (unsigned long long*)(w + b_rec); A.kb = (uint32_t*)(w + b_rec + b_vm); A.fstate = (uint32_t*)(w + b_rec + b_vm + b_kb);
+	A.tidx = bitmap ? (uint32_t*)(w + b_rec + b_vm + b_kb + b_fs) : nullptr; A.tpfd = tpfd;
 	A.n_frames = n_frames; A.nblk = nblk; A.maxR = (uint32_t)maxR;
 	uint32_t gx = (uint32_t)(((size_t)c->n_cu * 512 + n_frames - 1) / n_frames);
 	if (gx < 32) gx = 32;
@@ -2556,21 +2817,38 @@ static int parse_launch(agmv_hip_ctx* c, const uint8_t* d_bits, size_t stride, c
 	if (gx > maxR) gx = (uint32_t)maxR;
 	if (gx < 1) gx = 1;
 	const dim3 grid(gx, n_frames);
-	if (c->mode512) hipLaunchKernelGGL(k_fp_walk<true>, grid, dim3(64), 0, s, A);
-	else            hipLaunchKernelGGL(k_fp_walk<false>, grid, dim3(64), 0, s, A);
-	CK(hipGetLastError());
-	if (c->mode512) hipLaunchKernelGGL(k_fp_finish<true>, dim3(n_frames), dim3(64), 0, s, A);
-	else            hipLaunchKernelGGL(k_fp_finish<false>, dim3(n_frames), dim3(64), 0, s, A);
-	CK(hipGetLastError());
-	{
+	if (bitmap) CK(hipMemsetAsync(A.tidx, 0xFF, (size_t)n_frames * (tpfd + 1) * 4, s));   // TIDX_NONE
+	if (robust_only) {                                         // debugging aid: every frame through the robust kernels (bitmap form)
+		CK(hipMemsetD32Async((hipDeviceptr_t)A.fstate, (int)FS_BAD, n_frames, s));
+	} else {
+		if (c->mode512) hipLaunchKernelGGL(k_fp_walk<true>, grid, dim3(64), 0, s, A);
+		else            hipLaunchKernelGGL(k_fp_walk<false>, grid, dim3(64), 0, s, A);
+		CK(hipGetLastError());
+		if (c->mode512) hipLaunchKernelGGL(k_fp_finish<true>, dim3(n_frames), dim3(64), 0, s, A);
+		else            hipLaunchKernelGGL(k_fp_finish<false>, dim3(n_frames), dim3(64), 0, s, A);
+		CK(hipGetLastError());
+	}
+	c->d_fp_fstate = A.fstate; c->fp_frames = n_frames;
+	c->fp_vm = A.vm; c->fp_kb = A.kb; c->fp_tidx = A.tidx; c->fp_maxR = A.maxR;
+	if (!bitmap) {
 		uint32_t ge = gx;                                      // (a quarter / an eighth of it: 0.179 / 0.188 against 0.169 ms per 256 frames)
 		if (getenv("AGMV_EXPAND_GX")) ge = (uint32_t)atoi(getenv("AGMV_EXPAND_GX"));   // tuning aid
 		if (ge < 1) ge = 1;
 		hipLaunchKernelGGL(k_fp_expand, dim3(ge, n_frames), dim3(64), 0, s, A);
+		CK(hipGetLastError());
+		return parse_launch_robust(c, d_bits, stride, d_bpos, n_frames, nblk, d_offsets, d_nentered, ws_frames, A.fstate, s);
 	}
+	// bitmap form: the frames that could not be proven get their entry BITS from the robust kernels, are counted and
+	// numbered like the proven ones (k_fp_recount), then every frame's tile entries are looked up
+	if (parse_launch_robust(c, d_bits, stride, d_bpos, n_frames, nblk, nullptr, d_nentered, ws_frames, A.fstate, s, A.vm, A.maxR)) return -1;
+	hipLaunchKernelGGL(k_fp_recount, dim3(n_frames < 64u ? n_frames : 64u), dim3(64), 0, s, A);
 	CK(hipGetLastError());
-	c->d_fp_fstate = A.fstate; c->fp_frames = n_frames;
-	return parse_launch_robust(c, d_bits, stride, d_bpos, n_frames, nblk, d_offsets, d_nentered, ws_frames, A.fstate, s);
+	uint32_t gt = gx / 2 ? gx / 2 : 1;
+	if (getenv("AGMV_TILES_GX")) gt = (uint32_t)atoi(getenv("AGMV_TILES_GX"));   // tuning aid
+	if (gt < 1) gt = 1;
+	hipLaunchKernelGGL(k_fp_tiles, dim3(gt, n_frames), dim3(64), 0, s, A);
+	CK(hipGetLastError());
+	return 0;
 }
 
 extern "C" int agmv_hip_parse_frames_dev(agmv_hip_ctx* c, const uint8_t* d_bits, size_t stride, const uint32_t* d_bpos,
@@ -2641,16 +2919,28 @@ static int decode_prepare(agmv_hip_ctx* c, DecArgs& A, const uint8_t* d_bits, si
 static int decode_launch(agmv_hip_ctx* c, DecArgs A, uint32_t g0, uint32_t g1, hipStream_t s)   // GOPs [g0, g1) of the batch
 {
 	A.grp0 = g0;
-	if (c->mode512) hipLaunchKernelGGL(k_decode<true>, dim3((g1 - g0) * A.tpf), dim3(DEC_T), 0, s, A);
-	else            hipLaunchKernelGGL(k_decode<false>, dim3((g1 - g0) * A.tpf), dim3(DEC_T), 0, s, A);
+	const dim3 grid((g1 - g0) * A.tpf);
+	if (A.vm) {
+		if (c->mode512) hipLaunchKernelGGL((k_decode<true, true>), grid, dim3(DEC_T), 0, s, A);
+		else            hipLaunchKernelGGL((k_decode<false, true>), grid, dim3(DEC_T), 0, s, A);
+	} else {
+		if (c->mode512) hipLaunchKernelGGL((k_decode<true, false>), grid, dim3(DEC_T), 0, s, A);
+		else            hipLaunchKernelGGL((k_decode<false, false>), grid, dim3(DEC_T), 0, s, A);
+	}
 	CK(hipGetLastError());
 	return 0;
 }
 
 static int fixup_launch(agmv_hip_ctx* c, const DecArgs& A, hipStream_t s)
 {
-	if (c->mode512) hipLaunchKernelGGL(k_fixup<true>, dim3((A.nblk + 63) / 64), dim3(64), 0, s, A);
-	else            hipLaunchKernelGGL(k_fixup<false>, dim3((A.nblk + 63) / 64), dim3(64), 0, s, A);
+	const dim3 grid((A.nblk + 63) / 64);
+	if (A.vm) {
+		if (c->mode512) hipLaunchKernelGGL((k_fixup<true, true>), grid, dim3(64), 0, s, A);
+		else            hipLaunchKernelGGL((k_fixup<false, true>), grid, dim3(64), 0, s, A);
+	} else {
+		if (c->mode512) hipLaunchKernelGGL((k_fixup<true, false>), grid, dim3(64), 0, s, A);
+		else            hipLaunchKernelGGL((k_fixup<false, false>), grid, dim3(64), 0, s, A);
+	}
 	CK(hipGetLastError());
 	return 0;
 }
@@ -2720,6 +3010,54 @@ extern "C" int agmv_hip_parse_decode_frames_dev(agmv_hip_ctx* c, const uint8_t* 
 		}
 	}
 	if (fixup_launch(c, A, s)) return -1;
+	ev_mark(c, 7, s);
+	return 0;
+}
+
+// Parse + reconstruct without offsets[]: the parser's entry bitmaps go straight to k_decode, which ranks its own blocks in
+// them (k_fp_tiles tells every tile where it starts).  Against agmv_hip_parse_decode_frames_dev this drops k_fp_expand and
+// the 4 bytes per block it writes and k_decode reads back.  Batches of more than 65532 frames are cut at GOP boundaries
+// (the parser's grid has one row per frame); each part continues from the decoder state the part before it left.
+extern "C" int agmv_hip_decode_bitstreams_dev(agmv_hip_ctx* c, const uint8_t* d_bits, size_t stride, const uint32_t* d_bpos,
+                                              uint32_t n_frames, uint32_t w, uint32_t h, uint32_t first_fc,
+                                              uint32_t* d_nentered, uint32_t* d_out,
+                                              const uint32_t* d_prev, const uint32_t* d_prev_iframe, void* stream)
+{
+	if (need_ctx(c, true)) return -1;
+	if (check_geometry(w, h)) return -1;
+	if (n_frames == 0) return 0;
+	hipStream_t s = (hipStream_t)stream;
+	if (!d_nentered) {
+		if (n_frames > c->nent_cap) {
+			if (c->d_nent_own) CK(hipFree(c->d_nent_own));
+			c->d_nent_own = nullptr; c->nent_cap = 0;
+			CK(hipMalloc(&c->d_nent_own, (size_t)n_frames * 4));
+			c->nent_cap = n_frames;
+		}
+		d_nentered = c->d_nent_own;
+	}
+	const size_t npx = (size_t)w * h;
+	constexpr uint32_t PART = 65532u;                          // a multiple of 4
+	ev_mark(c, 6, s);
+	for (uint32_t f0 = 0; f0 < n_frames;) {
+		uint32_t f1 = n_frames;
+		if (f1 - f0 > PART) { f1 = f0 + PART; f1 -= (first_fc + f1) & 3u; }   // the next part starts with an I-frame
+		const uint32_t n = f1 - f0, fc = first_fc + f0;
+		// state before frame f0: the frame before it, and the snapshot taken at the last I-frame (the decoded I-frame itself, :401-405)
+		const uint32_t* prev = f0 == 0 ? d_prev : d_out + (size_t)(f0 - 1) * npx;
+		const uint32_t* previ = f0 == 0 ? d_prev_iframe : d_out + (size_t)(f0 - 4) * npx;
+		DecArgs A;
+		if (decode_prepare(c, A, d_bits + (size_t)f0 * stride, stride, d_bpos + f0, nullptr, d_nentered + f0, n, w, h, fc, d_out + (size_t)f0 * npx, prev, previ, s)) return -1;
+		ev_mark(c, 2, s);
+		if (parse_launch(c, d_bits + (size_t)f0 * stride, stride, d_bpos + f0, n, A.nblk, nullptr, d_nentered + f0, n, s, true)) return -1;
+		ev_mark(c, 3, s);
+		A.vm = c->fp_vm; A.kb = c->fp_kb; A.tidx = c->fp_tidx; A.maxR = c->fp_maxR;
+		ev_mark(c, 4, s);
+		if (decode_launch(c, A, 0, A.n_groups, s)) return -1;
+		if (fixup_launch(c, A, s)) return -1;
+		ev_mark(c, 5, s);
+		f0 = f1;
+	}
 	ev_mark(c, 7, s);
 	return 0;
 }

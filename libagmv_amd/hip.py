@@ -17,7 +17,7 @@ ABI_SYMBOLS = [
     "agmv_hip_last_error", "agmv_hip_set_palette", "agmv_hip_quantise_dev",
     "agmv_hip_encode_frames_dev", "agmv_hip_encode_frames", "agmv_hip_encode_entries_dev",
     "agmv_hip_encode_entries", "agmv_hip_nearest", "agmv_hip_within2_count", "agmv_hip_parse_frames_dev",
-    "agmv_hip_decode_frames_dev", "agmv_hip_parse_decode_frames_dev", "agmv_hip_parse_fallback_frames", "agmv_hip_decode_frames", "agmv_hip_decode_prior_dependent", "agmv_hip_synth_dev",
+    "agmv_hip_decode_frames_dev", "agmv_hip_parse_decode_frames_dev", "agmv_hip_decode_bitstreams_dev", "agmv_hip_parse_fallback_frames", "agmv_hip_decode_frames", "agmv_hip_decode_prior_dependent", "agmv_hip_synth_dev",
     "agmv_hip_interp_dev", "agmv_hip_histogram_dev", "agmv_hip_check", "agmv_hip_malloc",
     "agmv_hip_free", "agmv_hip_memcpy_h2d", "agmv_hip_memcpy_d2h", "agmv_hip_memset",
     "agmv_hip_sync", "agmv_hip_enable_timing", "agmv_hip_last_kernel_ms",
@@ -73,6 +73,9 @@ def load_library(path=None):
     L.agmv_hip_decode_frames_dev.argtypes = [vp, vp, sz, vp, vp, vp, u32, u32, u32, u32, vp, vp, vp, vp]
     L.agmv_hip_decode_frames.argtypes = [vp, vp, sz, vp, u32, u32, u32, u32, vp, vp, vp]
     L.agmv_hip_parse_decode_frames_dev.argtypes = [vp, vp, sz, vp, u32, u32, u32, u32, vp, vp, vp, vp, vp, vp]
+    if path is None or hasattr(L, "agmv_hip_decode_bitstreams_dev"):    # (an explicit `path` may be an older build kept for A/B timing, tools/variants/)
+        L.agmv_hip_decode_bitstreams_dev.argtypes = [vp, vp, sz, vp, u32, u32, u32, u32, vp, vp, vp, vp, vp]
+        L.agmv_hip_decode_bitstreams_dev.restype = C.c_int
     L.agmv_hip_decode_prior_dependent.argtypes = [vp, u32, u32, vp]
     L.agmv_hip_parse_fallback_frames.argtypes = [vp, vp]
     L.agmv_hip_parse_fallback_frames.restype = C.c_int
@@ -237,6 +240,19 @@ class AgmvHip:
             prev.data_ptr() if prev is not None else None,
             prev_iframe.data_ptr() if prev_iframe is not None else None, self._stream()))
         return out, offsets, nentered
+
+    def decode_bitstreams_dev(self, bits, bpos, n_frames, w, h, first_frame_count=0, out=None, nentered=None,
+                              prev=None, prev_iframe=None):
+        """parse + reconstruct without offsets[] (entry bitmaps straight into k_decode); returns the pixels"""
+        import torch
+        if out is None:
+            out = torch.empty((n_frames, h, w), dtype=torch.int32, device=bits.device)
+        self._ck(self.L.agmv_hip_decode_bitstreams_dev(
+            self.ctx, bits.data_ptr(), bits.stride(0), bpos.data_ptr(), n_frames, w, h, first_frame_count,
+            nentered.data_ptr() if nentered is not None else None, out.data_ptr(),
+            prev.data_ptr() if prev is not None else None,
+            prev_iframe.data_ptr() if prev_iframe is not None else None, self._stream()))
+        return out
 
     def decode_depends_on_prior(self, w, h):
         """after decode_dev: does any pixel of that batch derive from prev / prev_iframe (see agmv_hip.h)?"""

@@ -196,11 +196,24 @@ def gpu_decode(torch, hip, bits_list, pads, w, h, first_fc=0, prev=None, prev_if
     dbits = torch.from_numpy(bits).cuda()
     dbpos = torch.from_numpy(bpos).cuda()
     offs, nent = hip.parse_dev(dbits, dbpos, n, w, h)
-    out = hip.decode_dev(dbits, dbpos, offs, nent, n, w, h, first_fc,
-                         prev=dev_u32(torch, prev) if prev is not None else None,
-                         prev_iframe=dev_u32(torch, prev_iframe) if prev_iframe is not None else None)
+    dprev = dev_u32(torch, prev) if prev is not None else None
+    dprevi = dev_u32(torch, prev_iframe) if prev_iframe is not None else None
+    out = hip.decode_dev(dbits, dbpos, offs, nent, n, w, h, first_fc, prev=dprev, prev_iframe=dprevi)
+    same_without_offsets(torch, hip, dbits, dbpos, n, w, h, first_fc, dprev, dprevi, out, nent)
     torch.cuda.synchronize()
     return to_u32(out).reshape(n, -1), to_u32(offs), nent.cpu().numpy()
+
+
+def same_without_offsets(torch, hip, dbits, dbpos, n, w, h, first_fc, dprev, dprevi, ref_out, ref_nent):
+    """agmv_hip_decode_bitstreams_dev (entry bitmaps straight into k_decode, no offsets[]) must give the pixels and the
+    nentered[] of the two-call form -- every decode test goes through here, damaged streams included"""
+    nent2 = torch.full((n,), -1, dtype=torch.int32, device=dbits.device)
+    out2 = hip.decode_bitstreams_dev(dbits, dbpos, n, w, h, first_fc, nentered=nent2, prev=dprev, prev_iframe=dprevi)
+    torch.cuda.synchronize()
+    assert torch.equal(nent2, ref_nent), "nentered: bitmap form differs"
+    if not torch.equal(out2, ref_out):
+        bad = (out2 != ref_out).reshape(n, -1).any(dim=1).nonzero().flatten().tolist()
+        raise AssertionError("pixels: bitmap form differs in frames %s" % bad[:8])
 
 
 @pytest.mark.parametrize("mode512", [True, False])
@@ -492,6 +505,10 @@ def test_fuzz_parser_random_bytes(torch, hip, monkeypatch, seed):
     b = hip.decode_dev(dbits, dbpos, o_par, n_par, n, W, H, 0)
     torch.cuda.synchronize()
     assert torch.equal(a, b)
+    same_without_offsets(torch, hip, dbits, dbpos, n, W, H, 0, None, None, a, n_ser)
+    monkeypatch.setenv("AGMV_HIP_PARSE", "robust")            # ... and with every frame's entry bits from the robust kernels
+    same_without_offsets(torch, hip, dbits, dbpos, n, W, H, 0, None, None, a, n_ser)
+    monkeypatch.delenv("AGMV_HIP_PARSE", raising=False)
     if exp is not None:
         got = to_u32(b).reshape(n, -1)
         for f in range(n):
@@ -545,6 +562,8 @@ def test_parser_proof_repair_and_fallback(torch, hip, monkeypatch, mode512):
     dec_b, o_b, n_b = hip.parse_decode_dev(bits, bpos, 3, W, H)
     torch.cuda.synchronize()
     assert torch.equal(dec_a, dec_b) and torch.equal(o_b, o_par) and torch.equal(n_b, n_par)
+    same_without_offsets(torch, hip, bits, bpos, 3, W, H, 0, None, None, dec_a, n_par)       # (c) gets its entry bits from the robust kernels
+    assert hip.parse_fallback_frames() == 1
 
 
 @pytest.mark.parametrize("geom", [(3840, 2160, 4), (4, 4, 9), (2052, 4, 5), (8, 1024, 6)])
@@ -585,6 +604,7 @@ def test_parse_decode_in_ranges(torch, hip, monkeypatch, first_fc):
     offs, nent = hip.parse_dev(out, sizes, T, W, H)
     ref = hip.decode_dev(out, sizes, offs, nent, T, W, H, first_fc, prev=prev, prev_iframe=previ)
     torch.cuda.synchronize()
+    same_without_offsets(torch, hip, out, sizes, T, W, H, first_fc, prev, previ, ref, nent)
     for ns in ("1", "3", "5", "32"):
         monkeypatch.setenv("AGMV_DEC_SLICES", ns)
         dec, o2, n2 = hip.parse_decode_dev(out, sizes, T, W, H, first_fc, prev=prev, prev_iframe=previ)
@@ -644,6 +664,7 @@ def test_full_size_properties(torch, hip):
         assert torch.equal(h1[t, :sz[t]], out1[t, :sz[t]]) and torch.equal(h2[t, :sz[16 + t]], out1[16 + t, :sz[16 + t]])
     offs, nent = hip.parse_dev(out1, sz1, T, W, H)
     dec = hip.decode_dev(out1, sz1, offs, nent, T, W, H)
+    same_without_offsets(torch, hip, out1, sz1, T, W, H, 0, None, None, dec, nent)
     torch.cuda.synchronize()
     assert (nent.cpu().numpy() == W * H // 16).all()
     pal = torch.from_numpy(np.concatenate([p0, p1]).view(np.int32)).cuda()
@@ -706,6 +727,11 @@ def test_c3_full_batch_vs_oracle(torch, hip):
     dec = hip.decode_dev(out, sizes, offs, nent, T, W, H)
     torch.cuda.synchronize()
     assert hip.decode_depends_on_prior(W, H) is False
+    del offs
+    dec2 = hip.decode_bitstreams_dev(out, sizes, T, W, H)     # the form bench.py times: no offsets[]
+    torch.cuda.synchronize()
+    assert torch.equal(dec, dec2) and hip.parse_fallback_frames() == 0 and hip.decode_depends_on_prior(W, H) is False
+    del dec2
     sz = sizes.cpu().numpy()
     assert (nent.cpu().numpy() == W * H // 16).all() and (sz > 0).all() and (sz < hip.max_usize(W, H)).all()
     for g0 in (0, 508, 1020):
