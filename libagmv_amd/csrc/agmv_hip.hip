@@ -353,7 +353,7 @@ __device__ __forceinline__ uint32_t lookback(unsigned long long* st, int tile, i
 }
 
 constexpr int WBLK = 64;                                       // blocks per wave = slice of the workgroup tile
-constexpr size_t CTRL_BYTES = 256;                             // [0] ticket, [1] error, [32..42] phase stamps (ENC_PROF builds)
+constexpr size_t CTRL_BYTES = 1024;                            // dwords: [0] ticket, [1] error, [32..42] phase stamps (ENC_PROF builds), [64 + 16 s] ticket counter s of k_encode_w
 
 // K1.  Barrier-free dataflow form.  One workgroup = one tile of ENC_T consecutive 4x4 blocks (ENC_WAVES waves x 64
 // blocks), one lane = one block for classification/emission, carried through the <=4 frames of its GOP.  The stream of
@@ -392,6 +392,61 @@ typedef __attribute__((address_space(3))) uint32_t lds_u32;   // explicit LDS po
 __device__ __forceinline__ uint32_t lds_ld(const uint32_t* p) { return *(const volatile lds_u32*)p; }
 __device__ __forceinline__ void lds_st(uint32_t* p, uint32_t v) { *(volatile lds_u32*)p = v; }
 
+// Stores the compiler does not track: hipcc guards the data registers of a store it knows about with s_waitcnt vmcnt(0) before
+// they are written again, i.e. it waits for the write to be ACKNOWLEDGED (1-2 us for the status words, which go to the fabric)
+// -- three such waits per item in the look-back / copy-out sequence.  The hardware reads the data of a 4- / 8-byte store when
+// it issues it, and nothing in the wave waits for these stores, so they go out as asm (the compiler's waits for LOADS can only
+// become longer by it, never shorter: the memory counter retires in order).
+__device__ __forceinline__ void st_store_untracked(unsigned long long* p, unsigned long long v)
+{
+	asm volatile("global_store_dwordx2 %0, %1, off sc1" :: "v"(p), "v"(v) : "memory");      // = a relaxed agent-scope atomic store
+}
+__device__ __forceinline__ void store32_untracked(uint32_t* p, uint32_t v)
+{
+	asm volatile("global_store_dword %0, %1, off" :: "v"(p), "v"(v) : "memory");
+}
+__device__ __forceinline__ void store8_untracked(uint8_t* p, uint32_t v)
+{
+	asm volatile("global_store_byte %0, %1, off" :: "v"(p), "v"(v) : "memory");
+}
+// wave_copy_own with untracked stores
+__device__ __forceinline__ void wave_copy_own_u(const uint8_t* slot, uint8_t* gdst, uint32_t total, int lane)
+{
+	const uint32_t s = (uint32_t)((uintptr_t)gdst & 3u);
+	uint32_t head = s ? 4u - s : 0u;
+	if (head > total) head = total;
+	const uint32_t nbody = (total - head) >> 2, tail = (total - head) & 3u;
+	const uint8_t* sb = slot + 16 + head;
+	uint8_t* gb = gdst + head;
+	for (uint32_t d = lane; d < nbody; d += 64) store32_untracked((uint32_t*)(gb + 4u * d), *(const u32u*)(sb + 4u * d));
+	if ((uint32_t)lane < head) store8_untracked(gdst + lane, slot[16 + lane]);
+	const uint32_t tl = (uint32_t)lane - 8u;
+	if (tl < tail) store8_untracked(gb + 4u * nbody + tl, sb[4u * nbody + tl]);
+}
+// look-back of k_encode_w.  The common case -- every status word of the first window is published and one of them is a
+// prefix -- is straight-line code on the window the caller loaded long ago (`pre`); anything else goes through the general
+// loop above, out of line: inlined, its conditional reloads leave the compiler unsure whether a load is still pending at
+// every later write of those registers, and it answers each with s_waitcnt vmcnt(0) -- which at that point also waits for
+// the status / copy-out STORES in flight to be acknowledged (1-2 us each, three times per item).
+__device__ __noinline__ uint32_t lookback_slow(unsigned long long* st, int tile, int lane, uint32_t* ctrl, unsigned long long pre)
+{
+	return lookback(st, tile, lane, ctrl, pre);
+}
+__device__ __forceinline__ uint32_t lookback_w(unsigned long long* st, int tile, int lane, uint32_t* ctrl, unsigned long long pre)
+{
+	const uint32_t tag = (uint32_t)(pre >> 32), val = (uint32_t)pre;
+	const unsigned long long pm = __ballot(tag == 2u);
+	if (__all(tag != 0u) && pm != 0) {
+		const int first = __ffsll((long long)pm) - 1;
+		return wave_sum(lane <= first ? val : 0u);
+	}
+	return lookback_slow(st, tile, lane, ctrl, pre);
+}
+// status word of segment idx without a branch around the load (idx < 0, before the frame, reads word 0)
+__device__ __forceinline__ unsigned long long st_load_raw(unsigned long long* st, int idx)     // the caller substitutes ST_PREFIX for idx < 0
+{
+	return __hip_atomic_load(st + (idx >= 0 ? idx : 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 // wave-uniform bounded spin until the word at p satisfies (v >> shift) == tag; returns the word
 __device__ __forceinline__ uint32_t lds_wait(const uint32_t* p, uint32_t tag, int shift, uint32_t* ctrl, int lane)
 {
@@ -628,14 +683,13 @@ __global__ __launch_bounds__(ENC_T, ENC_WPE) ENC_WAVES_ATTR void k_encode(EncArg
 		auto resolve_prev = [&]() {                            // tile offset of item it-1, usize of the frame, gbase[]
 			unsigned long long* st = A.status + (size_t)p_f * A.tpf;
 			uint32_t excl = 0;
-			if (p_tile != 0) excl = lookback(st, (int)p_tile, lane, A.ctrl, pre);
+			// (straight-line look-back on the window loaded earlier; the general loop is out of line -- inlined, its conditional
+			//  reloads make the compiler drain the memory counter before gbase[] is published, i.e. the seven other waves of the
+			//  workgroup would wait for the acknowledgement of this wave's status stores: a fabric round trip per item)
+			if (p_tile != 0) excl = lookback_w(st, (int)p_tile, lane, A.ctrl, pre);
 			const uint32_t tot = lds_wait(&s_ctl[C_TTOTAL + pslot], ptag, 16, A.ctrl, lane) & 0xffffu;
-			if (lane == 0) {
-				if (p_tile != 0)
-					__hip_atomic_store(st + p_tile, ST_PREFIX | (unsigned long long)(excl + tot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-				if (p_tile == A.tpf - 1) A.sizes[p_f] = excl + tot;   // usize of the frame
-			}
-			// every wave of the tile has published its byte count (the tile total exists): exclusive scan over the waves
+			// every wave of the tile has published its byte count (the tile total exists): exclusive scan over the waves.
+			// gbase[] goes out FIRST: it is what the other waves wait for
 			const uint32_t ws = lane < ENC_WAVES ? (lds_ld(&s_ctl[C_WSUM + pslot * ENC_WAVES + lane]) & 0xffffu) : 0u;
 			uint32_t inc = ws;
 			inc += dpp_or0<0x111, 0xF>(inc);                    // the waves sit in the first lanes of row 0
@@ -647,6 +701,10 @@ __global__ __launch_bounds__(ENC_T, ENC_WPE) ENC_WAVES_ATTR void k_encode(EncArg
 				lds_st(gb, excl + inc - ws);
 				asm volatile("" ::: "memory");
 				lds_st(gb + 1, it);
+			}
+			if (lane == 0) {
+				if (p_tile != 0) st_store_untracked(st + p_tile, ST_PREFIX | (unsigned long long)(excl + tot));
+				if (p_tile == A.tpf - 1) store32_untracked(A.sizes + p_f, excl + tot);   // usize of the frame
 			}
 		};
 		auto copy_out_prev = [&]() {
@@ -664,7 +722,7 @@ __global__ __launch_bounds__(ENC_T, ENC_WPE) ENC_WAVES_ATTR void k_encode(EncArg
 			if (p_len == 0) return;
 			const uint32_t base = __builtin_amdgcn_readfirstlane(lds_ld(gb));
 			PSTAMP(6);
-			wave_copy_own(s_stage0 + (((it - 1) & 1) * ENC_WAVES + wave) * WSLOT, A.out + (size_t)p_f * A.out_stride + base, p_len, lane);
+			wave_copy_own_u(s_stage0 + (((it - 1) & 1) * ENC_WAVES + wave) * WSLOT, A.out + (size_t)p_f * A.out_stride + base, p_len, lane);
 		};
 
 		if (!cur.have) {                                       // final drain: item it-1 is the last one
@@ -714,6 +772,24 @@ __global__ __launch_bounds__(ENC_T, ENC_WPE) ENC_WAVES_ATTR void k_encode(EncArg
 #else
 #define LUT_OFF(c) lut_offset(c)
 #endif
+#if defined(ABL_LANEMASK) || defined(ABL_STATICSKIP)
+		// ablations (wrong bytes, timing only): look-ups for a subset of the lanes / none for the waves of the static quarter in P-frames
+		{
+#pragma unroll
+			for (int k = 0; k < 16; k++) eq[k] = 0;
+			bool doit = true;
+#ifdef ABL_STATICSKIP
+			if (!is_i && g.path == 0 && g.wbx + WBLK <= A.bw / 4) doit = false;    // (uniform)
+#endif
+#ifdef ABL_LANEMASK
+			if (((uint32_t)lane & (uint32_t)ABL_LANEMASK) != 0) doit = false;
+#endif
+			if (doit) {
+#pragma unroll
+				for (int k = 0; k < 16; k++) eq[k] = (uint16_t)__builtin_amdgcn_raw_buffer_load_b16(lut_rs, LUT_OFF(pxv[k]), 0, ENC_LUTAUX);
+			}
+		}
+#else
 #pragma unroll
 		for (int k = 0; k < 16; k++) {
 #ifdef ABL_NOGATHER
@@ -725,6 +801,7 @@ __global__ __launch_bounds__(ENC_T, ENC_WPE) ENC_WAVES_ATTR void k_encode(EncArg
 			}
 #endif
 		}
+#endif
 		PSTAMP(0);
 #ifdef ABL_SALU
 		{	// ablation: ABL_SALU extra scalar instructions per item (is scalar issue on the critical path?)
@@ -900,6 +977,334 @@ done:;
 	if (lane == 0)
 		for (int k = 0; k < 11; k++) atomicAdd(A.ctrl + 32 + k, k == 10 ? prof[k] : prof[k] >> 6);
 #endif
+}
+
+// ----------------------------------------------------------------------------------------------
+// K1, independent-wave form.  Same per-item work as k_encode above (look-ups with lane = (block, row), transpose,
+// lane = block classification, packed emission into the wave's stage slot, copy-out one item later), but NOTHING is
+// exchanged between the waves of a workgroup: a wave is its own "tile" of 64 consecutive blocks carried through the <= 4
+// frames of its GOP, publishes its own aggregate, runs its own decoupled look-back (over 64-block segments) and copies
+// its own bytes out.  The workgroup only shares the bit matrix in LDS.  What this buys over the dataflow form: no wait
+// for another wave's result anywhere (there a workgroup moves at the pace of its slowest wave in every item: a wave of
+// static or flat blocks gains nothing while its neighbours gather), and cheap and expensive segments average out
+// across the chip because every wave draws its next segment when it is done with the last.
+// Tickets: one per workgroup TILE of ENC_WAVES adjacent segments (wave w takes segment w of the tile: the rows the waves
+// stream are neighbours in memory), in tile-major order over the GOPs -- consecutive tickets are the same tile of
+// different GOPs, so a segment's predecessors are n_groups tickets old and mostly finished when a look-back reads them.
+// Wave 0 draws the ticket of the next tile when it enters a tile (the returning atomic then sits in ITS in-order memory
+// counter only, once per tile) and posts it in an LDS ring; the other waves pick it up when they get there -- the one
+// place where a wave reads something another wave of the workgroup wrote, a tile ahead of need.  Static assignments
+// (wave G takes segments G, G + NW, ...) and per-wave counters were measured and lost: the first makes a segment and its
+// predecessor run in the same round (look-backs spin), the second puts an atomic in every wave's memory counter.
+// Forward progress: a look-back waits for segments of tiles with LOWER tickets, drawn EARLIER by resident workgroups.
+// ----------------------------------------------------------------------------------------------
+constexpr int TKR = 8;                                         // ring of posted tickets (tiles a wave may lag behind wave 0)
+constexpr size_t ENCW_LDS_EXTRA = 2 * ENC_WAVES * WSLOT + 3 * TKR * 4;
+
+template <bool M512, bool ENTRIES>
+__global__ __launch_bounds__(ENC_T, ENC_WPE) ENC_WAVES_ATTR void k_encode_w(EncArgs A)
+{
+	constexpr int NROWS = M512 ? 512 : 256;
+	extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+	uint32_t* s_mtx = (uint32_t*)smem;                         // NROWS * MROW dwords
+	uint8_t* s_stage0 = smem + NROWS * MROW * 4;               // [ENC_WAVES][2] stage slots
+
+	const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+	const uint32_t npx = A.w * A.h;
+	const uint32_t spf = A.tpf;                                // segments (of WBLK blocks) per frame
+	const uint32_t jb = lane >> 2, prow = lane & 3;            // quantise phase: lane = (block jb of 16, row prow)
+	const __amdgpu_buffer_rsrc_t lut_rs = __builtin_amdgcn_make_buffer_rsrc((void*)A.lut, 0, (int)(LUT_ENTRIES * 2u), 0x00020000);
+
+	uint32_t* s_ctl = (uint32_t*)(s_stage0 + 2 * ENC_WAVES * WSLOT);   // [TKR][3] ticket ring: ticket, tile number + 1, waves that have read it
+	for (int i = tid; i < NROWS * MROW; i += ENC_T) s_mtx[i] = A.mtx[i];
+	if (tid < 3 * TKR) s_ctl[tid] = 0;
+	__syncthreads();
+	if (tid == 0) { s_ctl[0] = atomicAdd(A.ctrl, 1u); s_ctl[1] = 1u; }
+	__syncthreads();                                           // the only workgroup barriers of the kernel
+
+	auto locate = [&](const EncGeo& g, uint32_t B, uint32_t& qx, uint32_t& qy) {   // block index (>= wb_c) -> block column / row
+		if (B >= A.nblk) B = A.nblk - 1;                       // blocks past the frame re-use the last valid one
+		qx = g.wbx + (B - g.wb_c); qy = g.wby;
+		while (qx >= A.bw) { qx -= A.bw; qy++; }
+	};
+	const uint32_t tiles_pf = (spf + ENC_WAVES - 1) / ENC_WAVES;   // tiles per frame
+	const uint32_t total_tk = tiles_pf * A.n_groups;
+	auto setup = [&](uint32_t t, EncGeo& g) -> bool {
+		const uint32_t tl = t / A.n_groups, group = t - tl * A.n_groups;
+		g.tile = tl * ENC_WAVES + (uint32_t)wave;              // the segment
+		if (g.tile >= spf) return false;                       // (the last tile of a frame may be short: nothing for this wave)
+		g.f_lo = group == 0 ? 0 : (int)(group * 4 - A.phase);
+		g.f_hi = (int)(group * 4 - A.phase) + 4;
+		if (g.f_hi > (int)A.n_frames) g.f_hi = (int)A.n_frames;
+		g.wbase = g.tile * WBLK;
+		g.wb_c = g.wbase < A.nblk ? g.wbase : A.nblk - 1;
+		g.wby = __builtin_amdgcn_readfirstlane(g.wb_c / A.bw); g.wbx = g.wb_c - g.wby * A.bw;
+		const uint32_t blk = g.wbase + lane;
+		g.valid = blk < A.nblk;
+		uint32_t bx, by;
+		locate(g, blk, bx, by);
+		g.poff = by * 4 * A.w + bx * 4;
+		uint32_t qy0;
+		locate(g, g.wbase + jb, g.qx0, qy0);
+		g.p0b = ((qy0 * 4 + prow) * A.w + g.qx0 * 4) * 4u;
+		g.path = (g.wbase + WBLK > A.nblk || g.wbx + WBLK > 2 * A.bw) ? 2 : (g.wbx + WBLK > A.bw ? 1 : 0);
+		return true;
+	};
+	auto load_frame = [&](const EncGeo& g, const uint32_t* fp, uint4 (&dst)[4]) {
+		const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)fp, 0, (int)(npx * 4u), 0x00020000);
+		const uint32_t w3b = 12u * A.w;
+		if (g.path == 0) {
+#pragma unroll
+			for (int i = 0; i < 4; i++) dst[i] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rs, g.p0b + 256 * i, 0, ENC_PIXAUX));
+		} else if (g.path == 1) {
+#pragma unroll
+			for (int i = 0; i < 4; i++)
+				dst[i] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rs, g.p0b + 256 * i + (g.qx0 + 16 * i >= A.bw ? w3b : 0u), 0, ENC_PIXAUX));
+		} else {
+#pragma unroll
+			for (int i = 0; i < 4; i++) {
+				uint32_t qx, qy;
+				locate(g, g.wbase + jb + 16 * i, qx, qy);
+				dst[i] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rs, ((qy * 4 + prow) * A.w + qx * 4) * 4u, 0, ENC_PIXAUX));
+			}
+		}
+	};
+
+	// ---- tickets (see the header comment): ring slot s & (TKR-1) holds {ticket, s + 1} of the workgroup's s-th tile and
+	// counts the waves that have read it; wave 0 refills a slot only when all of them have
+	uint32_t seq = 0;                                          // tiles this wave has taken
+	uint32_t pend = 0, pend_seq = 0;                           // wave 0: the ticket requested for tile pend_seq (lane 0's register until posted)
+	bool pending = false;
+	auto post_ticket = [&]() {                                 // wave 0: hand the requested ticket to the others (waits for the atomic)
+		if (wave == 0 && pending) {
+			const uint32_t tv = __builtin_amdgcn_readfirstlane(pend);
+			if (lane == 0) {
+				uint32_t* tw = &s_ctl[(pend_seq & (TKR - 1)) * 3];
+				lds_st(tw, tv);
+				asm volatile("" ::: "memory");
+				lds_st(tw + 1, pend_seq + 1);
+			}
+			pending = false;
+		}
+	};
+	auto take_ticket = [&](EncGeo& g) -> bool {
+		for (;;) {
+			const uint32_t sq = seq;
+			uint32_t* tw = &s_ctl[(sq & (TKR - 1)) * 3];
+			post_ticket();
+			lds_wait(tw + 1, sq + 1, 0, A.ctrl, lane);
+			asm volatile("" ::: "memory");
+			const uint32_t t = __builtin_amdgcn_readfirstlane(lds_ld(tw));
+			if (lane == 0) atomicAdd(tw + 2, 1u);
+			seq = sq + 1;
+			if (t >= total_tk) return false;                   // (wave 0 requests nothing behind the end: every wave stops at this slot)
+			if (wave == 0) {
+				uint32_t* nw = &s_ctl[((sq + 1) & (TKR - 1)) * 3];
+				if (sq + 1 >= TKR) {                               // the slot still belongs to tile sq + 1 - TKR until every wave has read it
+					lds_wait(nw + 2, ENC_WAVES, 0, A.ctrl, lane);
+					if (lane == 0) lds_st(nw + 2, 0u);
+				}
+				if (lane == 0) pend = atomicAdd(A.ctrl, 1u);
+				pend_seq = sq + 1; pending = true;
+			}
+			if (setup(t, g)) return true;
+		}
+	};
+	// cursors over the wave's sequence of (segment, frame) items: `pf` = the item whose pixels are requested next, `nxt` = the
+	// item whose pixels are in flight (one ahead of the item being encoded)
+	struct Cursor { EncGeo g; int f; bool have; };
+	Cursor cur, nxt, pf;
+	auto advance = [&](Cursor& c) {                            // to the next item of the wave
+		if (c.f + 1 < c.g.f_hi) { c.f++; return; }
+		c.have = take_ticket(c.g);
+		c.f = c.have ? c.g.f_lo : 0;
+	};
+	pf.have = take_ticket(pf.g);
+	pf.f = pf.have ? pf.g.f_lo : 0;
+	uint32_t it = 0;
+	uint32_t ip[8];                                            // the GOP's I-frame entries of this block, two u16 per register
+	uint4 px[4];
+	nxt = pf;
+	if (pf.have) { load_frame(pf.g, A.pix + (size_t)pf.f * npx, px); advance(pf); }
+	bool have_prev = false;                                    // item it-1: segment, frame, bytes of this wave
+	uint32_t p_seg = 0, p_len = 0;
+	int p_f = 0;
+	uint8_t* const myslots = s_stage0 + (size_t)wave * 2 * WSLOT;
+
+	for (;;) {
+		// (L) the look-back window of item it-1 is requested first: it has landed when this item's look-ups have
+		unsigned long long pre = ST_PREFIX;                    // (L) the look-back window of item it-1: requested BEHIND this item's look-ups, see there
+		auto finish_prev = [&]() {                             // frame offset of item it-1, its prefix published, its bytes copied out
+			unsigned long long* st = A.status + (size_t)p_f * spf;
+			uint32_t excl = 0;
+#ifdef ABLW_NOSTATUS
+			if (false) {
+#else
+			if (p_seg != 0) {
+#endif
+				asm volatile("" : "+v"(pre));                  // (the select below stays here: ahead of this point it would wait for the window right behind its request)
+#ifdef ABLW_NOLOOKBACK
+				excl = 0;
+#else
+				excl = lookback_w(st, (int)p_seg, lane, A.ctrl, (int)p_seg - 1 - lane >= 0 ? pre : ST_PREFIX);
+#endif
+#ifdef ABLW_FEWSTORES
+				if (lane == 0 && wave == 0) st_store_untracked(st + p_seg, ST_PREFIX | (unsigned long long)(excl + p_len));
+#else
+				if (lane == 0) st_store_untracked(st + p_seg, ST_PREFIX | (unsigned long long)(excl + p_len));
+#endif
+			}
+			if (p_seg == spf - 1 && lane == 0) store32_untracked(A.sizes + p_f, excl + p_len);   // usize of the frame
+#ifndef ABLW_NOCOPY
+			if (p_len) wave_copy_own_u(myslots + ((it - 1) & 1) * WSLOT, A.out + (size_t)p_f * A.out_stride + excl, p_len, lane);
+#endif
+		};
+		cur = nxt;                                             // the item whose pixels are in px
+		if (!cur.have) {                                       // final drain: item it-1 is the last one
+#ifndef ABLW_NOSTATUS
+			if (have_prev && p_seg != 0) pre = st_load_raw(A.status + (size_t)p_f * spf, (int)p_seg - 1 - lane);
+#endif
+			if (have_prev) finish_prev();
+			break;
+		}
+		EncGeo& g = cur.g;
+		const int f = cur.f;
+		const bool new_tile = f == g.f_lo;
+		const bool is_i = ((A.first_fc + f) & 3u) == 0;
+		uint8_t* wslot = myslots + (it & 1) * WSLOT;           // free since this wave's copy-out of item it-2
+		uint8_t* scratch = wslot + 16;
+		if (new_tile) {
+			if (((A.first_fc + g.f_lo) & 3u) != 0) {           // GOP started in an earlier batch
+#pragma unroll
+				for (int r = 0; r < 4; r++) {
+					const uint2 q = *(const uint2*)(A.ientries_in + g.poff + r * A.w);
+					ip[2 * r] = q.x; ip[2 * r + 1] = q.y;
+				}
+			} else {
+#pragma unroll
+				for (int m = 0; m < 8; m++) ip[m] = 0;
+			}
+		}
+#if ENC_PRIO
+		__builtin_amdgcn_s_setprio(ENC_PRIO);
+#endif
+		// ---- (Q) colour -> entry through the exact table, lane = (block, row)
+		uint32_t eq[16];
+		const uint32_t pxv[16] = {px[0].x, px[0].y, px[0].z, px[0].w, px[1].x, px[1].y, px[1].z, px[1].w,
+		                          px[2].x, px[2].y, px[2].z, px[2].w, px[3].x, px[3].y, px[3].z, px[3].w};
+#pragma unroll
+		for (int k = 0; k < 16; k++) {
+			if (ENTRIES) eq[k] = pxv[k] & (M512 ? 0x1FFu : 0xFFu);
+			else eq[k] = (uint16_t)__builtin_amdgcn_raw_buffer_load_b16(lut_rs, lut_offset(pxv[k]), 0, ENC_LUTAUX);
+		}
+		// The status words bypass the caches (agent-scope atomics: a fabric round trip, 1-2 us) and a wave's memory counter
+		// retires in order: ahead of the look-ups, every wait for an entry would wait for that round trip first (measured:
+		// 1.05 against 0.7x ms per 256 frames).  Behind them it is the youngest load while the entries are awaited, and has
+		// this item's classification and emission to land in.
+		asm volatile("" ::: "memory");
+#if !defined(ABLW_NOSTATUS) && !defined(ABLW_NOLOOKBACK)
+		pre = st_load_raw(A.status + (size_t)p_f * spf, (int)p_seg - 1 - lane);   // unconditional (no item before this one: word 0 of frame 0, unused): under a branch the compiler could not count it and would drain it with the last look-up
+#endif
+		asm volatile("" ::: "memory");
+#if ENC_PRIO
+		__builtin_amdgcn_s_setprio(0);
+#endif
+		// [block][pixel] u16 table in the wave's scratch; a lane writes its row: 8 bytes at i*512 + lane*8
+#pragma unroll
+		for (int i = 0; i < 4; i++) {
+			uint2 q;
+			q.x = eq[i * 4 + 0] | (eq[i * 4 + 1] << 16);
+			q.y = eq[i * 4 + 2] | (eq[i * 4 + 3] << 16);
+			*(uint2*)(scratch + i * 512 + lane * 8) = q;
+		}
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+		__builtin_amdgcn_wave_barrier();
+		// ---- transpose: lane = block reads its 16 entries (32 contiguous bytes), kept PACKED two per register
+		uint32_t ep[8];
+		{
+			const uint4 lo = *(const uint4*)(scratch + lane * 32), hi = *(const uint4*)(scratch + lane * 32 + 16);
+			ep[0] = lo.x; ep[1] = lo.y; ep[2] = lo.z; ep[3] = lo.w; ep[4] = hi.x; ep[5] = hi.y; ep[6] = hi.z; ep[7] = hi.w;
+		}
+		post_ticket();                                         // (wave 0: the ticket it requested before these look-ups has landed with them)
+		// ---- (C) block tests: count1 = CompareIFrameBlock vs the top-left entry colour (src/agmv_encode.c:302-352),
+		// count2 = ComparePFrameBlock vs the I-frame entries (src/agmv_encode.c:240-300); one matrix bit per pixel
+		const uint32_t e0 = ep[0] & 0xffffu, row0 = e0 * MROW;
+		uint32_t acc1 = 0, acc2 = 0, nesc = 0;
+		if (is_i) block_tests<M512, false>(ep, ip, s_mtx, row0, acc1, acc2, nesc);
+		else block_tests<M512, true>(ep, ip, s_mtx, row0, acc1, acc2, nesc);
+		const uint32_t count1 = __popc(acc1), count2 = __popc(acc2);
+		const bool copy = !is_i && count2 >= COPY_COUNT;       // COPY has priority, :465
+		const bool fill = !copy && count1 >= FILL_COUNT;
+		uint32_t len;
+		if (copy) len = 1;
+		else if (fill) len = M512 ? (2u + ((e0 & 0xffu) >= 127u ? 1u : 0u)) : 2u;
+		else len = 17u + nesc;
+		if (!g.valid) len = 0;
+
+		if (is_i) {                                            // iframe_entries = img_entry, :626-630
+#pragma unroll
+			for (int m = 0; m < 8; m++) ip[m] = ep[m];
+			if (A.ientries_out && (uint32_t)f == A.last_iframe && g.valid) {
+#pragma unroll
+				for (int r = 0; r < 4; r++) {
+					uint2 q;
+					q.x = ep[2 * r]; q.y = ep[2 * r + 1];
+					*(uint2*)(A.ientries_out + g.poff + r * A.w) = q;
+				}
+			}
+		}
+		// ---- byte offsets inside the wave; the segment's aggregate goes to the status row at once
+		const uint32_t incl = wave_incl_scan(len, lane);
+		const uint32_t wtot = __builtin_amdgcn_readlane(incl, 63);
+#ifndef ABLW_NOSTATUS
+#ifdef ABLW_FEWSTORES
+		if (lane == 0) st_store_untracked(A.status + (size_t)f * spf + g.tile, (g.tile == 0 || wave != 0 ? ST_PREFIX : ST_AGG) | wtot);   // (ablation: every word reads as a prefix, so nobody waits for the prefix stores that are left out)
+#else
+		if (lane == 0) st_store_untracked(A.status + (size_t)f * spf + g.tile, (g.tile == 0 ? ST_PREFIX : ST_AGG) | wtot);
+#endif
+#endif
+		// ---- (E) emit this block's bytes into the wave's stage slot (see k_encode above for the byte-pair trick)
+		if (g.valid) {
+			uint8_t* sp = wslot + 16 + incl - len;
+			if (!copy && !fill) {
+				if (M512) {
+					uint32_t n = 0;                                // escape bytes so far
+#pragma unroll
+					for (int m = 0; m < 8; m++) {
+						const uint32_t p = ep[m], idx2 = p & 0x00FF00FFu;
+						const u16x2 c2 = __builtin_elementwise_min(__builtin_bit_cast(u16x2, idx2), __builtin_bit_cast(u16x2, 0x007F007Fu));
+						const uint32_t code2 = ((p >> 1) & 0x00800080u) | __builtin_bit_cast(uint32_t, c2);   // :395-401
+						const uint32_t w = __builtin_amdgcn_perm(code2, p, 0x02060004u);   // code_lo, idx_lo, code_hi, idx_hi
+						const uint32_t e2 = idx2 + 0x00810081u;    // bit 8 / bit 24: index >= 127
+						*(u16u*)(sp + n + (1 + 2 * m)) = (uint16_t)w;
+						n += (e2 >> 8) & 1u;
+						*(u16u*)(sp + n + (2 + 2 * m)) = (uint16_t)(w >> 16);
+						n += e2 >> 24;
+					}
+				} else {
+#pragma unroll
+					for (int m = 0; m < 4; m++)                    // :428-429
+						*(u32u*)(sp + 1 + 4 * m) = __builtin_amdgcn_perm(ep[2 * m + 1], ep[2 * m], 0x06040200u);
+				}
+			} else if (fill) {
+				if (M512) {
+					const uint32_t idx = e0 & 0xffu, p7 = (e0 >> 1) & 0x80u;
+					*(u16u*)(sp + 1) = (uint16_t)(p7 | (idx < 127u ? idx : 127u) | (idx << 8));   // :382-388
+				} else {
+					sp[1] = (uint8_t)e0;                           // :421
+				}
+			}
+			asm volatile("" ::: "memory");
+			sp[0] = copy ? COPY_FLAG : (fill ? FILL_FLAG : NORMAL_FLAG);
+		}
+		if (have_prev) finish_prev();
+		// ---- the next item's pixels, into the registers this item's pixels left
+		asm volatile("" ::: "memory");
+		have_prev = true; p_seg = g.tile; p_f = f; p_len = wtot;
+		it++;
+		nxt = pf;
+		if (pf.have) { load_frame(pf.g, A.pix + (size_t)pf.f * npx, px); advance(pf); }
+	}
 }
 
 // ----------------------------------------------------------------------------------------------
@@ -2554,7 +2959,10 @@ static int encode_dev(agmv_hip_ctx* c, const uint32_t* d_pix, uint32_t n_frames,
 	A.pix = d_pix; A.out = d_out; A.sizes = d_sizes; A.lut = c->d_lut; A.mtx = c->d_mtx; A.ientries_in = d_ientries; A.ientries_out = d_ientries;
 	A.out_stride = out_stride;
 	A.n_frames = n_frames; A.w = w; A.h = h; A.bw = w / 4; A.nblk = (w / 4) * (h / 4);
-	A.tpf = (A.nblk + ENC_T - 1) / ENC_T;
+	// two forms of the kernel: the workgroup dataflow (k_encode, default) and independent waves (k_encode_w; AGMV_ENC_KERNEL=w)
+	const char* ek = getenv("AGMV_ENC_KERNEL");
+	const bool wform = ek && strcmp(ek, "w") == 0;
+	A.tpf = wform ? (A.nblk + WBLK - 1) / WBLK : (A.nblk + ENC_T - 1) / ENC_T;   // segments of 64 blocks / tiles of ENC_T blocks per frame
 	A.first_fc = first_fc; A.phase = first_fc & 3u;
 	A.n_groups = (n_frames + A.phase + 3) / 4;
 	A.total_tiles = A.n_groups * A.tpf;
@@ -2593,10 +3001,13 @@ static int encode_dev(agmv_hip_ctx* c, const uint32_t* d_pix, uint32_t n_frames,
 	CK(hipMemsetAsync(c->d_status, 0, need * sizeof(unsigned long long), s));
 	CK(hipMemsetAsync(c->d_ctrl, 0, CTRL_BYTES, s));
 	uint32_t grid = (uint32_t)c->enc_grid;
-	if (grid > A.total_tiles) grid = A.total_tiles;
-	const size_t lds = (size_t)(c->mode512 ? 512 : 256) * MROW * 4 + ENC_LDS_EXTRA;
-	void (*kern)(EncArgs) = c->mode512 ? (entries ? k_encode<true, true> : k_encode<true, false>)
-	                                   : (entries ? k_encode<false, true> : k_encode<false, false>);
+	const uint32_t work = wform ? (A.total_tiles + ENC_WAVES - 1) / ENC_WAVES : A.total_tiles;
+	if (grid > work) grid = work;
+	const size_t lds = (size_t)(c->mode512 ? 512 : 256) * MROW * 4 + (wform ? ENCW_LDS_EXTRA : ENC_LDS_EXTRA);
+	void (*kern)(EncArgs) = wform ? (c->mode512 ? (entries ? k_encode_w<true, true> : k_encode_w<true, false>)
+	                                            : (entries ? k_encode_w<false, true> : k_encode_w<false, false>))
+	                              : (c->mode512 ? (entries ? k_encode<true, true> : k_encode<true, false>)
+	                                            : (entries ? k_encode<false, true> : k_encode<false, false>));
 	CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
 	ev_mark(c, 0, s);
 	hipLaunchKernelGGL(kern, dim3(grid), dim3(ENC_T), lds, s, A);
