@@ -2,7 +2,8 @@
 """bench.py -- the AGMV hot path on MI355X: frames/s encode+decode, and the HBM roofline of the
 dominant kernel, next to the reference CPU path timed on the same box.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c3|c2|c5] [--frames T]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c3|c2|c5] [--frames T] [--backend nccl|gloo]
+                  [--no-cpu-baseline] [--no-normal-heavy] [--no-secondary]
   N > 1:  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
               --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -43,9 +44,14 @@ def parse_args():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="c3", choices=["c3", "c2", "c5"])
-    ap.add_argument("--normal-heavy", action="store_true",
-                    help="also time k_encode on a NORMAL-heavy variant of the clip (reported as roofline_normal_heavy; off by default so "
-                         "that a profile of the default command holds the headline launches only)")
+    ap.add_argument("--no-normal-heavy", action="store_true",
+                    help="skip the k_encode run on a NORMAL-heavy variant of the clip (roofline_normal_heavy; it runs AFTER the timed region -- "
+                         "use this switch for a profile that should hold the headline launches only)")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="skip the 320x240 lines (secondary.c2: the 156 encoded frames of config 2; secondary.c2_large: 8192 frames), "
+                         "which also run after the timed region")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="torch.distributed backend for N > 1 (nccl = RCCL over xGMI; gloo lets several ranks share ONE card to rehearse the multi-rank path)")
     ap.add_argument("--frames", type=int, default=0, help="frames per GPU (default: the workload's)")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="weak: every rank its own clip of --frames frames; strong: ONE clip of --frames frames split over the ranks by GOP range")
@@ -74,37 +80,83 @@ def host_lib():
     return L
 
 
-def cpu_baseline(wl, p0, p1, frames_np, gpu_bits, gpu_pix=None):
-    """the reference's own compiled loops (oracle/_ref, kind 'reference') or, where that build is absent, the
-    oracle restatement (kind 'port') on a bounded sample of the same clip, one host thread.  The DECODE leg is always
-    the restatement ('port': the compiled reference's decoder is file-coupled to its LZ stage), which the tests pin
-    against the reference; `legs` says which is which.  Also a free parity check: the sample's bitstreams AND decoded
-    pixels must equal what the GPU produced for those frames."""
+def cpu_baseline(wl, p0, p1, frames_np, gpu_bits, gpu_pix=None, gpu_decode=None):
+    """the reference's own compiled code (oracle/_ref, kind 'reference') or, where that build is absent, the oracle
+    restatement (kind 'port') on a bounded sample of the same clip, one host thread.
+      encode leg: AGMV_FindNearestEntry per pixel + AGMV_Assemble{I,P}FrameBitstream (loops A+B of AGMV_EncodeFrame);
+      decode leg: the reference's AGMV_DecodeFrameChunk (src/agmv_decode.c:145-410) on a .agmv file holding the sample's
+                  chunks -- the GPU's bitstreams, which the encode leg has just shown equal to the reference's, compressed
+                  by libagmv.so's exact LZSS (the reference's own O(n * 65535) LZSS would take minutes for the sample).
+                  Its time includes the reference's LZSS-decode stage, which stays on the host on our side too.
+    `legs` says which code ran each leg.  Also a parity check: the bitstreams must equal the GPU's, and the pixels must equal
+    what the GPU (gpu_decode) makes of the SAME decompressed bytes -- the reference's LZSS stores floor(bits / 8) as csize, so
+    a decompressed stream can come out a byte short and the frame then keeps some of the previous frame's pixels
+    (src/agmv_decode.c:229-232): part of the format, and exactly what agmv_hip_decode_bitstreams_dev reproduces."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracles as O
     W, H = wl["W"], wl["H"]
     kind = "reference" if O.have_ref() else "port"
     enc = (O.RefEncoder if kind == "reference" else O.OracleEncoder)(W, H, True, p0, p1)
-    dec = O.OracleDecoder(W, H, True, p0, p1)
     t_enc = t_dec = 0.0
+    bits = []
     for k, f in enumerate(frames_np):
         t0 = time.perf_counter()
         b = enc.encode(f)
-        t1 = time.perf_counter()
-        pix = dec.decode(b)
-        t2 = time.perf_counter()
-        t_enc += t1 - t0
-        t_dec += t2 - t1
+        t_enc += time.perf_counter() - t0
+        bits.append(b)
         if gpu_bits is not None and not (len(b) == len(gpu_bits[k]) and (b == gpu_bits[k]).all()):
             raise SystemExit("bench: GPU bitstream of frame %d differs from the %s CPU path" % (k, kind))
-        if gpu_pix is not None and not (pix == gpu_pix[k]).all():
-            raise SystemExit("bench: GPU decode of frame %d differs from the CPU decoder" % k)
     n = len(frames_np)
+    dec_kind = kind
+    if kind == "reference":
+        import tempfile
+        import hostlib as HL
+        L = O.ref()
+        a = L.refshim_create(W, H, O.OPT_III, O.LZSS, np.ascontiguousarray(p0, np.uint32), np.ascontiguousarray(p1, np.uint32))
+        tmp = os.path.join(tempfile.mkdtemp(prefix="agmv_bench_"), "sample.agmv")
+        L.refshim_write_header(a, tmp.encode())
+        L.refshim_destroy(a)
+        with open(tmp, "ab") as fh:
+            for k, b in enumerate(bits):
+                comp, cs = HL.lzss(b)
+                fh.write(b"AGFC" + np.array([k + 1, len(b), cs], "<u4").tobytes() + comp.tobytes() + b"\xff" * 8)
+        err = C.c_int(0)
+        w_, h_, n_, v_ = (C.c_uint32(0) for _ in range(4))
+        d = L.refshim_decoder_open(tmp.encode(), C.byref(err), C.byref(w_), C.byref(h_), C.byref(n_), C.byref(v_))
+        if err.value != 0:
+            raise SystemExit("bench: the reference decoder rejected the sample file (error %d)" % err.value)
+        pix = np.zeros(W * H, np.uint32)
+        ref_pix, ref_bits, ref_bpos = [], [], []
+        bp = C.c_uint32(0)
+        for k in range(n):
+            t0 = time.perf_counter()
+            e = L.refshim_decoder_next(d, pix.ctypes.data_as(C.c_void_p), None, None, C.byref(bp))
+            t_dec += time.perf_counter() - t0
+            if e != 0:
+                raise SystemExit("bench: the reference decoder failed on frame %d (error %d)" % (k, e))
+            bs = np.zeros(bp.value + 16, np.uint8)
+            L.refshim_decoder_bitstream(d, bs, len(bs))           # what its LZ stage left in the persistent buffer (+ the stale bytes behind)
+            ref_pix.append(pix.copy()); ref_bits.append(bs); ref_bpos.append(bp.value)
+        if gpu_decode is not None:
+            got = gpu_decode(ref_bits, ref_bpos)
+            for k in range(n):
+                if not (got[k] == ref_pix[k]).all():
+                    raise SystemExit("bench: GPU decode of frame %d differs from the reference's AGMV_DecodeFrameChunk" % k)
+        L.refshim_decoder_close(d)
+        os.unlink(tmp)
+    else:
+        dec = O.OracleDecoder(W, H, True, p0, p1)
+        for k, b in enumerate(bits):
+            t0 = time.perf_counter()
+            pix = dec.decode(b)
+            t_dec += time.perf_counter() - t0
+            if gpu_pix is not None and not (pix == gpu_pix[k]).all():
+                raise SystemExit("bench: GPU decode of frame %d differs from the CPU decoder" % k)
     return {"value": round(n / (t_enc + t_dec), 4), "unit": "frames/s", "cores": 1, "kind": kind,
-            "legs": {"encode": kind, "decode": "port"},
+            "legs": {"encode": kind, "decode": dec_kind},
             "sample": "first %d encoded frames of the same clip (%dx%d): AGMV_FindNearestEntry per pixel + "
-                      "Assemble{I,P}FrameBitstream (%.2f s/frame) then parse+reconstruct (%.4f s/frame); "
-                      "LZSS excluded on both sides" % (n, W, H, t_enc / n, t_dec / n),
+                      "Assemble{I,P}FrameBitstream (%.2f s/frame), then AGMV_DecodeFrameChunk = LZSS-decode + parse + reconstruct "
+                      "(%.4f s/frame); the LZSS ENCODER excluded on both sides" % (n, W, H, t_enc / n, t_dec / n),
             "host_cores_available": os.cpu_count()}
 
 
@@ -120,8 +172,13 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "gloo":
+            local_rank = local_rank % max(1, torch.cuda.device_count())        # rehearsal: the ranks share the cards there are
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("gloo")
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     elif args.gpus > 1:
         raise SystemExit("bench: for --gpus N > 1 launch with torch.distributed.run (see the docstring)")
     torch.cuda.set_device(local_rank)
@@ -282,9 +339,21 @@ def main():
             f_np = frames[:n_cpu].cpu().numpy().view(np.uint32)
             gpu_bits = [out[f, :int(usz[f])].cpu().numpy() for f in range(n_cpu)]
             gpu_pix = [dec[f].cpu().numpy().view(np.uint32).reshape(-1) for f in range(n_cpu)]
-            res["cpu_baseline"] = cpu_baseline(wl, p0, p1, list(f_np), gpu_bits, gpu_pix)
-        if args.normal_heavy and world == 1 and npx > 500000 and args.scaling == "weak":     # (last: it re-uses the bitstream slab)
+            def gpu_decode(bits_list, bpos_list):              # the same decompressed bytes through the GPU path
+                stride_s = (max(len(b) for b in bits_list) + 255) & ~255
+                slab = np.zeros((len(bits_list), stride_s), np.uint8)
+                for k, b in enumerate(bits_list):
+                    slab[k, :len(b)] = b
+                px = hip.decode_bitstreams_dev(torch.from_numpy(slab).to(dev), torch.tensor(bpos_list, dtype=torch.int32, device=dev),
+                                               len(bits_list), W, H, first_fc)
+                torch.cuda.synchronize()
+                return px.cpu().numpy().view(np.uint32).reshape(len(bits_list), -1)
+            res["cpu_baseline"] = cpu_baseline(wl, p0, p1, list(f_np), gpu_bits, gpu_pix, gpu_decode)
+        if not args.no_normal_heavy and world == 1 and npx > 500000 and args.scaling == "weak":     # (after the timed region: it re-uses the bitstream slab)
             res["roofline_normal_heavy"] = normal_heavy_leg(torch, hip, frames, W, H, first_fc, out, sizes)
+        if not args.no_secondary and world == 1 and args.workload == "c3" and args.scaling == "weak":
+            del dec
+            res["secondary"] = secondary_legs(torch, local_rank, dev)
         print(json.dumps(res))
     if dist is not None:
         dist.barrier()
@@ -313,6 +382,66 @@ def normal_heavy_leg(torch, hip, frames, W, H, first_fc, out, sizes, n=256):
     return {"kernel": "k_encode", "achieved": round(alg / (t * 1e-3) / 1e9, 1), "frac": round(alg / (t * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
             "avg_launch_ms": round(t, 4), "algorithmic_bytes_per_launch": alg,
             "sample": "first %d frames of the clip XOR 3 bits of noise per channel (mean usize %d bytes)" % (n, int(sizes[:n].float().mean()))}
+
+
+def secondary_legs(torch, local_rank, dev):
+    """north_star's other resolution, 320x240, after the timed region: the clip of config 2 (212 source frames -> the 156
+    encoded frames of AGMV_EncodeAGMV's light PDIFS schedule) and a machine-filling batch (8192 frames).  Kernel times from
+    HIP events (median of 5 launches after 2), fractions of the 8 TB/s HBM peak on algorithmic bytes like the headline."""
+    from libagmv_amd import AgmvHip
+    W, H = 320, 240
+    npx = W * H
+    h2 = AgmvHip(local_rank)
+    out = {}
+    try:
+        src = h2.synth_dev(W, H, 1, 212, device=dev)
+        pick, i = [], 1
+        while i <= 212:
+            pick += [(i, -1), (i + 1, i + 2), (i + 3, -1)]
+            i += 4
+            if i + 4 >= 212:
+                break
+        c2 = torch.empty((len(pick), H, W), dtype=torch.int32, device=dev)
+        for k, (a, b) in enumerate(pick):
+            c2[k] = src[a - 1] if b < 0 else h2.interp_dev(src[a - 1], src[b - 1])
+        hist = h2.histogram_dev(src.reshape(-1), 3)
+        torch.cuda.synchronize()
+        p0 = np.zeros(256, np.uint64)
+        p1 = np.zeros(256, np.uint64)
+        host_lib().AGMV_BuildPalette(hist.cpu().numpy().view(np.uint32).ctypes.data, 3, 3, p0.ctypes.data, p1.ctypes.data)
+        h2.set_palette(p0.astype(np.uint32), p1.astype(np.uint32), True)
+        h2.enable_timing(True)
+        big = h2.synth_dev(W, H, 0, 8192, device=dev)
+        for name, clip in (("c2", c2), ("c2_large", big)):
+            n = clip.shape[0]
+            bits = torch.empty((n, h2.max_usize(W, H)), dtype=torch.uint8, device=dev)
+            sizes = torch.empty(n, dtype=torch.int32, device=dev)
+            nent = torch.empty(n, dtype=torch.int32, device=dev)
+            pix = torch.empty((n, H, W), dtype=torch.int32, device=dev)
+            ms = {"e": [], "p": [], "d": []}
+            wall = []
+            for it in range(7):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                h2.encode_dev(clip, n, W, H, 0, out=bits, sizes=sizes)
+                h2.decode_bitstreams_dev(bits, sizes, n, W, H, 0, out=pix, nentered=nent)
+                torch.cuda.synchronize()
+                if it >= 2:
+                    wall.append(time.perf_counter() - t0)
+                    ms["e"].append(h2.last_kernel_ms(0)); ms["p"].append(h2.last_kernel_ms(1)); ms["d"].append(h2.last_kernel_ms(2))
+            h2.check()
+            assert (nent.cpu().numpy() == npx // 16).all()
+            alg = 4 * npx * n + int(sizes.cpu().numpy().astype(np.int64).sum())
+            e, p, d = (float(np.median(ms[k])) for k in ("e", "p", "d"))
+            fr = lambda t: round(alg / (t * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+            out[name] = {"frames": int(n), "width": W, "height": H, "algorithmic_bytes": alg,
+                         "kernels_ms": {"k_encode": round(e, 4), "parser": round(p, 4), "k_decode+k_fixup": round(d, 4)},
+                         "encode_frac": fr(e), "decode_frac": fr(d), "parse_decode_frac": fr(p + d),
+                         "frames_per_s_encode_decode": round(n / float(np.median(wall)), 1)}
+            del bits, pix
+    finally:
+        h2.close()
+    return out
 
 
 if __name__ == "__main__":

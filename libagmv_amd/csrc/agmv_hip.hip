@@ -23,6 +23,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <pthread.h>
 
 #include "../../include/agmv_hip.h"
 
@@ -65,26 +66,7 @@ extern "C" const char* agmv_hip_last_error(void) { return g_err; }
 #ifndef ENC_LUTAUX
 #define ENC_LUTAUX 0          /* cache policy of the table look-ups */
 #endif
-#ifndef ENC_MAXWPE
-#define ENC_MAXWPE 0          /* != 0: tell the compiler that no more than this many waves share a SIMD anyway (LDS bounds the residency), so it may spend registers on keeping LDS reads in flight */
-#endif
-#if ENC_MAXWPE
-#define ENC_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(ENC_MAXWPE, ENC_MAXWPE)))
-#else
-#define ENC_WAVES_ATTR
-#endif
-#ifndef ENC_ORDER
-#define ENC_ORDER 0           /* ticket -> (tile, GOP): 0 tile-major over all GOPs, 1 GOP-major, 2 tile-major inside bands of ENC_BAND GOPs */
-#endif
-#ifndef ENC_BAND
-#define ENC_BAND 16
-#endif
-#ifndef ENC_PFDEPTH
-#define ENC_PFDEPTH 1         /* items whose pixels are in flight per wave (the loop is unrolled by this many register sets); 2 measured the same as 1 (0.716 vs 0.719 ms per 256 frames): the wait is not the latency of one load */
-#endif
-#ifndef ENC_PFLATE
-#define ENC_PFLATE 3          /* where the next item's pixel loads are issued: 0 behind the look-ups, 1 after emit (ahead of the tile-offset wait), 2 after classify, 3 after the copy-out (measured best: synth 0.730 vs 0.768 ms per 256 frames) */
-#endif
+constexpr int ENC_PFDEPTH = 1;     // items whose pixels are in flight per wave (the loop is unrolled by this many register sets); 2 measured the same as 1
 constexpr int ENC_T = ENC_T_OVERRIDE;          // threads per encode workgroup = 4x4 blocks per tile
 constexpr int ENC_WAVES = ENC_T / 64;
 static_assert(ENC_WAVES >= 1 && ENC_WAVES <= 16, "the per-wave offsets are scanned inside one 16-lane row");
@@ -98,12 +80,9 @@ constexpr int DEC_T = DEC_T_OVERRIDE;          // threads per decode workgroup
 #endif
 constexpr int DEC_STAGE = DEC_T * DEC_BPB;   // LDS window for a tile's bitstream bytes in ONE frame (24 B per block; beyond it bytes come from global memory); x4 frames = 24 KB, 5 workgroups per CU
 constexpr int DEC_SR = DEC_STAGE / 4 / DEC_T;   // dwords of the window each lane carries from global memory to LDS
-#ifndef LUT_SPARSE
-#define LUT_SPARSE 1
-#endif
 constexpr int DEC_MAX_SLICES = 32;           // agmv_hip_parse_decode_frames_dev: GOP ranges whose parse overlaps the reconstruction of the range before
 constexpr uint32_t LUT_COLOURS = 1u << 24;
-constexpr uint32_t LUT_ENTRIES = LUT_SPARSE == 1 ? (1u << 28) : (1u << 24);   // index space of the table (see lut_index)
+constexpr uint32_t LUT_ENTRIES = 1u << 28;   // index space of the table (see lut_index): 32 MiB populated in 512 MiB
 
 constexpr unsigned long long ST_AGG = 1ull << 32;     // look-back status tags (high word)
 constexpr unsigned long long ST_PREFIX = 2ull << 32;
@@ -115,6 +94,7 @@ struct agmv_hip_ctx {
 	uint16_t* d_lut;                // 2^24 entries
 	uint32_t* d_mtx;                // 512 * MROW dwords
 	uint32_t* d_pal;                // 512 colours (p0 | p1)
+	struct lut_share* share;        // owner of the three tables above (shared between the contexts of a device that hold the same palette)
 	unsigned long long* d_status;   // look-back words
 	size_t status_cap;              // in words
 	uint32_t* d_ctrl;               // [0] ticket, [1] error, padded to 16 B
@@ -164,34 +144,21 @@ extern "C" size_t agmv_hip_max_usize(uint32_t w, uint32_t h, int mode512)
 // R,G,B table).  index = R[7:2] G[7:2] B[7:2] | R[1:0] G[1:0] B[1:0]
 __host__ __device__ __forceinline__ uint32_t lut_index(uint32_t px)
 {
-#if LUT_SPARSE == 2
-	return px & 0xFFFFFFu;                                     // plain R, G, B order: a 128-byte line = 64 consecutive B at one (R, G)
-#elif LUT_SPARSE
 	// same 4x4x4 cubes, but the cube number keeps the 2-bit holes of the masked pixel (R6 .. G6 .. B6): 6 VALU per
 	// look-up instead of 12; the table spans 512 MiB of address space, 32 MiB of it populated (8 KiB runs every 32 KiB)
 	return ((px & 0xFCFCFCu) << 4) | ((((px & 0x030303u) * 0x10410u) >> 16) & 0x3Fu);
-#else
-	return (px & 0xFC0000u) | ((px & 0xFC00u) << 2) | ((px & 0xFCu) << 4) | (px & 3u) | ((px >> 6) & 0xCu) |
-	       ((px >> 12) & 0x30u);
-#endif
 }
 
 // byte offset of a colour's entry, = 2 * lut_index(px), in 5 VALU for the sparse form (and, mul, bfe, and, lshl_or):
 // bit 15 of the product is always 0, so the 7-bit field at bit 15 is the in-cube index already doubled
 __device__ __forceinline__ uint32_t lut_offset(uint32_t px)
 {
-#if LUT_SPARSE == 2
-	return (px << 8) >> 7;
-#elif LUT_SPARSE
 	const uint32_t m = __umul24(px & 0x030303u, 0x10410u);       // full-rate 24-bit multiply (a 32-bit v_mul_lo is quarter rate)
 	const uint32_t hi = px & 0xFCFCFCu;
 	uint32_t lo, off;                                          // spelled out: the compiler turns this into 4 instructions otherwise
 	asm("v_bfe_u32 %0, %1, 15, 7" : "=v"(lo) : "v"(m));
 	asm("v_lshl_or_b32 %0, %1, 5, %2" : "=v"(off) : "v"(hi), "v"(lo));
 	return off;
-#else
-	return lut_index(px) * 2u;
-#endif
 }
 
 // ----------------------------------------------------------------------------------------------
@@ -280,11 +247,7 @@ struct EncArgs {
 // s_waitcnt vmcnt(0): every prefetch and every output store in flight would have to land before the barrier.
 __device__ __forceinline__ void lds_barrier()
 {
-#ifdef ABL_FULLBARRIER
-	__syncthreads();
-#else
 	asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-#endif
 }
 
 // Wave-wide scans on the VALU's DPP lanes (row shifts inside the 16-lane rows, then the two row broadcasts gfx9 has
@@ -353,7 +316,7 @@ __device__ __forceinline__ uint32_t lookback(unsigned long long* st, int tile, i
 }
 
 constexpr int WBLK = 64;                                       // blocks per wave = slice of the workgroup tile
-constexpr size_t CTRL_BYTES = 1024;                            // dwords: [0] ticket, [1] error, [32..42] phase stamps (ENC_PROF builds), [64 + 16 s] ticket counter s of k_encode_w
+constexpr size_t CTRL_BYTES = 1024;                            // dwords: [0] ticket, [1] error, [32..42] phase stamps (ENC_PROF builds), the rest: lab builds
 
 // K1.  Barrier-free dataflow form.  One workgroup = one tile of ENC_T consecutive 4x4 blocks (ENC_WAVES waves x 64
 // blocks), one lane = one block for classification/emission, carried through the <=4 frames of its GOP.  The stream of
@@ -423,7 +386,7 @@ __device__ __forceinline__ void wave_copy_own_u(const uint8_t* slot, uint8_t* gd
 	const uint32_t tl = (uint32_t)lane - 8u;
 	if (tl < tail) store8_untracked(gb + 4u * nbody + tl, sb[4u * nbody + tl]);
 }
-// look-back of k_encode_w.  The common case -- every status word of the first window is published and one of them is a
+// look-back of k_encode's duty wave.  The common case -- every status word of the first window is published and one of them is a
 // prefix -- is straight-line code on the window the caller loaded long ago (`pre`); anything else goes through the general
 // loop above, out of line: inlined, its conditional reloads leave the compiler unsure whether a load is still pending at
 // every later write of those registers, and it answers each with s_waitcnt vmcnt(0) -- which at that point also waits for
@@ -515,7 +478,7 @@ struct EncGeo {
 // are skipped and classification + emission run on the caller's entries (AGMV_AssembleIFrameBitstream /
 // AGMV_AssemblePFrameBitstream on a given AGMV_ENTRY plane, src/agmv_encode.c:354-527).
 template <bool M512, bool ENTRIES>
-__global__ __launch_bounds__(ENC_T, ENC_WPE) ENC_WAVES_ATTR void k_encode(EncArgs A)
+__global__ __launch_bounds__(ENC_T, ENC_WPE) void k_encode(EncArgs A)
 {
 	constexpr int NROWS = M512 ? 512 : 256;
 	extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -544,19 +507,8 @@ __global__ __launch_bounds__(ENC_T, ENC_WPE) ENC_WAVES_ATTR void k_encode(EncArg
 	// geometry: ONE integer division per wave (of its first block, wave-uniform); lane positions follow by adding and
 	// wrapping at the end of a block row (no per-lane divisions)
 	auto setup = [&](uint32_t t, EncGeo& g) {
-#if ENC_ORDER == 1
-		const uint32_t group = t / A.tpf;                      // GOP-major: consecutive tickets are consecutive tiles of one GOP (adjacent memory)
-		g.tile = t - group * A.tpf;
-#elif ENC_ORDER == 2
-		// bands of ENC_BAND GOPs, tile-major inside a band
-		const uint32_t band = t / (A.tpf * ENC_BAND), r = t - band * (A.tpf * ENC_BAND);
-		const uint32_t gb = A.n_groups - band * ENC_BAND < ENC_BAND ? A.n_groups - band * ENC_BAND : ENC_BAND;   // GOPs in this band
-		g.tile = r / gb;
-		const uint32_t group = band * ENC_BAND + (r - g.tile * gb);
-#else
 		g.tile = t / A.n_groups;
 		const uint32_t group = t - g.tile * A.n_groups;
-#endif
 		g.f_lo = group == 0 ? 0 : (int)(group * 4 - A.phase);
 		g.f_hi = (int)(group * 4 - A.phase) + 4;
 		if (g.f_hi > (int)A.n_frames) g.f_hi = (int)A.n_frames;
@@ -579,9 +531,6 @@ __global__ __launch_bounds__(ENC_T, ENC_WPE) ENC_WAVES_ATTR void k_encode(EncArg
 		g.path = (g.wbase + WBLK > A.nblk || g.wbx + WBLK > 2 * A.bw) ? 2 : (g.wbx + WBLK > A.bw ? 1 : 0);
 	};
 	auto load_frame = [&](const EncGeo& g, const uint32_t* fp, uint4 (&dst)[4]) {
-#ifdef ABL_PXHOT
-		fp = A.pix;                                            // ablation: every item reads frame 0 (L2 / Infinity-Cache hits instead of HBM)
-#endif
 		const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)fp, 0, (int)(npx * 4u), 0x00020000);
 		const uint32_t w3b = 12u * A.w;
 		if (g.path == 0) {
@@ -708,16 +657,11 @@ __global__ __launch_bounds__(ENC_T, ENC_WPE) ENC_WAVES_ATTR void k_encode(EncArg
 			}
 		};
 		auto copy_out_prev = [&]() {
-#ifdef ABL_NOCOPYOUT
-			return;
-#endif
 			// EVERY wave waits here, also one with nothing to copy: this wait is what bounds the drift between the waves
 			// (see the header comment) -- a wave of blocks past the end of the frame must not run rounds ahead and recycle
 			// control slots the others still read
 			const uint32_t* gb = &s_ctl[C_GBASE + (pslot * ENC_WAVES + wave) * 2];
-#ifndef ABL_NOSYNC
 			lds_wait(gb + 1, it, 0, A.ctrl, lane);
-#endif
 			asm volatile("" ::: "memory");
 			if (p_len == 0) return;
 			const uint32_t base = __builtin_amdgcn_readfirstlane(lds_ld(gb));
@@ -767,63 +711,17 @@ __global__ __launch_bounds__(ENC_T, ENC_WPE) ENC_WAVES_ATTR void k_encode(EncArg
 		uint32_t eq[16];
 		const uint32_t pxv[16] = {px[0].x, px[0].y, px[0].z, px[0].w, px[1].x, px[1].y, px[1].z, px[1].w,
 		                          px[2].x, px[2].y, px[2].z, px[2].w, px[3].x, px[3].y, px[3].z, px[3].w};
-#ifdef ABL_SMALLLUT
-#define LUT_OFF(c) (lut_offset(c) & 0x1FFFFEu)
-#else
 #define LUT_OFF(c) lut_offset(c)
-#endif
-#if defined(ABL_LANEMASK) || defined(ABL_STATICSKIP)
-		// ablations (wrong bytes, timing only): look-ups for a subset of the lanes / none for the waves of the static quarter in P-frames
-		{
-#pragma unroll
-			for (int k = 0; k < 16; k++) eq[k] = 0;
-			bool doit = true;
-#ifdef ABL_STATICSKIP
-			if (!is_i && g.path == 0 && g.wbx + WBLK <= A.bw / 4) doit = false;    // (uniform)
-#endif
-#ifdef ABL_LANEMASK
-			if (((uint32_t)lane & (uint32_t)ABL_LANEMASK) != 0) doit = false;
-#endif
-			if (doit) {
-#pragma unroll
-				for (int k = 0; k < 16; k++) eq[k] = (uint16_t)__builtin_amdgcn_raw_buffer_load_b16(lut_rs, LUT_OFF(pxv[k]), 0, ENC_LUTAUX);
-			}
-		}
-#else
 #pragma unroll
 		for (int k = 0; k < 16; k++) {
-#ifdef ABL_NOGATHER
-			eq[k] = pxv[k] & 0x1FFu;
-#else
 			if (ENTRIES) eq[k] = pxv[k] & (M512 ? 0x1FFu : 0xFFu);
 			else {
 				eq[k] = (uint16_t)__builtin_amdgcn_raw_buffer_load_b16(lut_rs, LUT_OFF(pxv[k]), 0, ENC_LUTAUX);
 			}
-#endif
 		}
-#endif
 		PSTAMP(0);
-#ifdef ABL_SALU
-		{	// ablation: ABL_SALU extra scalar instructions per item (is scalar issue on the critical path?)
-			uint32_t sx = (uint32_t)it;
-#pragma unroll
-			for (int z = 0; z < ABL_SALU; z++) asm volatile("s_add_u32 %0, %0, 1" : "+s"(sx) :: "scc");
-			if (sx == 0x12345u) prof_sink = sx;
-		}
-#endif
-#ifdef ABL_VALU
-		{	// ablation: ABL_VALU extra (independent of everything) vector instructions per item
-			uint32_t vx = (uint32_t)lane;
-#pragma unroll
-			for (int z = 0; z < ABL_VALU; z++) asm volatile("v_add_u32 %0, %0, 1" : "+v"(vx));
-			if (vx == 0x12345u) prof_sink = vx;
-		}
-#endif
 		// issued right BEHIND the look-ups (the memory counter retires in order: ahead of them they would have to land
 		// before the first entry is usable), and before the wait for the entries
-#if ENC_PFLATE == 0
-		prefetch_next();
-#endif
 #if ENC_PRIO
 		__builtin_amdgcn_s_setprio(0);
 #endif
@@ -854,12 +752,8 @@ __global__ __launch_bounds__(ENC_T, ENC_WPE) ENC_WAVES_ATTR void k_encode(EncArg
 		uint32_t acc1 = 0, acc2 = 0, nesc = 0;
 		// (the I / P choice is wave-uniform: unswitched by hand -- with the test inside the unrolled loop the compiler
 		//  branches per entry pair and waits for each pair's two matrix words before it issues the next reads)
-#ifdef ABL_NOCMP
-		acc1 = 0xFFFFu; acc2 = 0xFFFFu; (void)row0;                   // ablation: every block FILL / COPY without reading the matrix
-#else
 		if (is_i) block_tests<M512, false>(ep, ip, s_mtx, row0, acc1, acc2, nesc);
 		else block_tests<M512, true>(ep, ip, s_mtx, row0, acc1, acc2, nesc);
-#endif
 		const uint32_t count1 = __popc(acc1), count2 = __popc(acc2);
 		const bool copy = !is_i && count2 >= COPY_COUNT;       // COPY has priority, :465
 		const bool fill = !copy && count1 >= FILL_COUNT;
@@ -903,19 +797,12 @@ __global__ __launch_bounds__(ENC_T, ENC_WPE) ENC_WAVES_ATTR void k_encode(EncArg
 			}
 		}
 		PSTAMP(4);
-#if ENC_PFLATE == 2
-		prefetch_next();
-#endif
 		// ---- (E) emit this block's bytes into the wave's stage slot
 		// Codes are built two at a time in packed 16-bit lanes and written as {code, index} byte PAIRS at byte-granular
 		// LDS addresses (gfx950 runs DS in unaligned mode): when an entry has no escape byte its pair's second byte is
 		// overwritten by the next pair, and the one byte a block may spill past its end is the next block's flag --
 		// which is why the flags are written last.  The LDS unit executes a wave's writes in program order.
-#ifdef ABL_NOEMIT
-		if (false) {
-#else
 		if (g.valid) {
-#endif
 			uint8_t* sp = wslot + 16 + incl - len;
 			if (!copy && !fill) {
 				if (M512) {
@@ -949,13 +836,8 @@ __global__ __launch_bounds__(ENC_T, ENC_WPE) ENC_WAVES_ATTR void k_encode(EncArg
 			sp[0] = copy ? COPY_FLAG : (fill ? FILL_FLAG : NORMAL_FLAG);
 		}
 		PSTAMP(5);
-#if ENC_PFLATE == 1
-		prefetch_next();                                       // ahead of the wait for the tile offset: an issue that blocks on a full memory pipeline blocks nothing else here
-#endif
 		if (have_prev) copy_out_prev();
-#if ENC_PFLATE == 3
 		prefetch_next();
-#endif
 		PSTAMP(7);
 
 		// ---- next item
@@ -970,342 +852,15 @@ __global__ __launch_bounds__(ENC_T, ENC_WPE) ENC_WAVES_ATTR void k_encode(EncArg
 			if (!body(pxs[d])) goto done;
 	}
 done:;
-#if defined(ABL_SALU) || defined(ABL_VALU)
-	if (prof_sink == 0x12345u) A.ctrl[3] = prof_sink;
-#endif
 #ifdef ENC_PROF
 	if (lane == 0)
 		for (int k = 0; k < 11; k++) atomicAdd(A.ctrl + 32 + k, k == 10 ? prof[k] : prof[k] >> 6);
 #endif
 }
 
-// ----------------------------------------------------------------------------------------------
-// K1, independent-wave form.  Same per-item work as k_encode above (look-ups with lane = (block, row), transpose,
-// lane = block classification, packed emission into the wave's stage slot, copy-out one item later), but NOTHING is
-// exchanged between the waves of a workgroup: a wave is its own "tile" of 64 consecutive blocks carried through the <= 4
-// frames of its GOP, publishes its own aggregate, runs its own decoupled look-back (over 64-block segments) and copies
-// its own bytes out.  The workgroup only shares the bit matrix in LDS.  What this buys over the dataflow form: no wait
-// for another wave's result anywhere (there a workgroup moves at the pace of its slowest wave in every item: a wave of
-// static or flat blocks gains nothing while its neighbours gather), and cheap and expensive segments average out
-// across the chip because every wave draws its next segment when it is done with the last.
-// Tickets: one per workgroup TILE of ENC_WAVES adjacent segments (wave w takes segment w of the tile: the rows the waves
-// stream are neighbours in memory), in tile-major order over the GOPs -- consecutive tickets are the same tile of
-// different GOPs, so a segment's predecessors are n_groups tickets old and mostly finished when a look-back reads them.
-// Wave 0 draws the ticket of the next tile when it enters a tile (the returning atomic then sits in ITS in-order memory
-// counter only, once per tile) and posts it in an LDS ring; the other waves pick it up when they get there -- the one
-// place where a wave reads something another wave of the workgroup wrote, a tile ahead of need.  Static assignments
-// (wave G takes segments G, G + NW, ...) and per-wave counters were measured and lost: the first makes a segment and its
-// predecessor run in the same round (look-backs spin), the second puts an atomic in every wave's memory counter.
-// Forward progress: a look-back waits for segments of tiles with LOWER tickets, drawn EARLIER by resident workgroups.
-// ----------------------------------------------------------------------------------------------
-constexpr int TKR = 8;                                         // ring of posted tickets (tiles a wave may lag behind wave 0)
-constexpr size_t ENCW_LDS_EXTRA = 2 * ENC_WAVES * WSLOT + 3 * TKR * 4;
-
-template <bool M512, bool ENTRIES>
-__global__ __launch_bounds__(ENC_T, ENC_WPE) ENC_WAVES_ATTR void k_encode_w(EncArgs A)
-{
-	constexpr int NROWS = M512 ? 512 : 256;
-	extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-	uint32_t* s_mtx = (uint32_t*)smem;                         // NROWS * MROW dwords
-	uint8_t* s_stage0 = smem + NROWS * MROW * 4;               // [ENC_WAVES][2] stage slots
-
-	const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-	const uint32_t npx = A.w * A.h;
-	const uint32_t spf = A.tpf;                                // segments (of WBLK blocks) per frame
-	const uint32_t jb = lane >> 2, prow = lane & 3;            // quantise phase: lane = (block jb of 16, row prow)
-	const __amdgpu_buffer_rsrc_t lut_rs = __builtin_amdgcn_make_buffer_rsrc((void*)A.lut, 0, (int)(LUT_ENTRIES * 2u), 0x00020000);
-
-	uint32_t* s_ctl = (uint32_t*)(s_stage0 + 2 * ENC_WAVES * WSLOT);   // [TKR][3] ticket ring: ticket, tile number + 1, waves that have read it
-	for (int i = tid; i < NROWS * MROW; i += ENC_T) s_mtx[i] = A.mtx[i];
-	if (tid < 3 * TKR) s_ctl[tid] = 0;
-	__syncthreads();
-	if (tid == 0) { s_ctl[0] = atomicAdd(A.ctrl, 1u); s_ctl[1] = 1u; }
-	__syncthreads();                                           // the only workgroup barriers of the kernel
-
-	auto locate = [&](const EncGeo& g, uint32_t B, uint32_t& qx, uint32_t& qy) {   // block index (>= wb_c) -> block column / row
-		if (B >= A.nblk) B = A.nblk - 1;                       // blocks past the frame re-use the last valid one
-		qx = g.wbx + (B - g.wb_c); qy = g.wby;
-		while (qx >= A.bw) { qx -= A.bw; qy++; }
-	};
-	const uint32_t tiles_pf = (spf + ENC_WAVES - 1) / ENC_WAVES;   // tiles per frame
-	const uint32_t total_tk = tiles_pf * A.n_groups;
-	auto setup = [&](uint32_t t, EncGeo& g) -> bool {
-		const uint32_t tl = t / A.n_groups, group = t - tl * A.n_groups;
-		g.tile = tl * ENC_WAVES + (uint32_t)wave;              // the segment
-		if (g.tile >= spf) return false;                       // (the last tile of a frame may be short: nothing for this wave)
-		g.f_lo = group == 0 ? 0 : (int)(group * 4 - A.phase);
-		g.f_hi = (int)(group * 4 - A.phase) + 4;
-		if (g.f_hi > (int)A.n_frames) g.f_hi = (int)A.n_frames;
-		g.wbase = g.tile * WBLK;
-		g.wb_c = g.wbase < A.nblk ? g.wbase : A.nblk - 1;
-		g.wby = __builtin_amdgcn_readfirstlane(g.wb_c / A.bw); g.wbx = g.wb_c - g.wby * A.bw;
-		const uint32_t blk = g.wbase + lane;
-		g.valid = blk < A.nblk;
-		uint32_t bx, by;
-		locate(g, blk, bx, by);
-		g.poff = by * 4 * A.w + bx * 4;
-		uint32_t qy0;
-		locate(g, g.wbase + jb, g.qx0, qy0);
-		g.p0b = ((qy0 * 4 + prow) * A.w + g.qx0 * 4) * 4u;
-		g.path = (g.wbase + WBLK > A.nblk || g.wbx + WBLK > 2 * A.bw) ? 2 : (g.wbx + WBLK > A.bw ? 1 : 0);
-		return true;
-	};
-	auto load_frame = [&](const EncGeo& g, const uint32_t* fp, uint4 (&dst)[4]) {
-		const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)fp, 0, (int)(npx * 4u), 0x00020000);
-		const uint32_t w3b = 12u * A.w;
-		if (g.path == 0) {
-#pragma unroll
-			for (int i = 0; i < 4; i++) dst[i] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rs, g.p0b + 256 * i, 0, ENC_PIXAUX));
-		} else if (g.path == 1) {
-#pragma unroll
-			for (int i = 0; i < 4; i++)
-				dst[i] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rs, g.p0b + 256 * i + (g.qx0 + 16 * i >= A.bw ? w3b : 0u), 0, ENC_PIXAUX));
-		} else {
-#pragma unroll
-			for (int i = 0; i < 4; i++) {
-				uint32_t qx, qy;
-				locate(g, g.wbase + jb + 16 * i, qx, qy);
-				dst[i] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rs, ((qy * 4 + prow) * A.w + qx * 4) * 4u, 0, ENC_PIXAUX));
-			}
-		}
-	};
-
-	// ---- tickets (see the header comment): ring slot s & (TKR-1) holds {ticket, s + 1} of the workgroup's s-th tile and
-	// counts the waves that have read it; wave 0 refills a slot only when all of them have
-	uint32_t seq = 0;                                          // tiles this wave has taken
-	uint32_t pend = 0, pend_seq = 0;                           // wave 0: the ticket requested for tile pend_seq (lane 0's register until posted)
-	bool pending = false;
-	auto post_ticket = [&]() {                                 // wave 0: hand the requested ticket to the others (waits for the atomic)
-		if (wave == 0 && pending) {
-			const uint32_t tv = __builtin_amdgcn_readfirstlane(pend);
-			if (lane == 0) {
-				uint32_t* tw = &s_ctl[(pend_seq & (TKR - 1)) * 3];
-				lds_st(tw, tv);
-				asm volatile("" ::: "memory");
-				lds_st(tw + 1, pend_seq + 1);
-			}
-			pending = false;
-		}
-	};
-	auto take_ticket = [&](EncGeo& g) -> bool {
-		for (;;) {
-			const uint32_t sq = seq;
-			uint32_t* tw = &s_ctl[(sq & (TKR - 1)) * 3];
-			post_ticket();
-			lds_wait(tw + 1, sq + 1, 0, A.ctrl, lane);
-			asm volatile("" ::: "memory");
-			const uint32_t t = __builtin_amdgcn_readfirstlane(lds_ld(tw));
-			if (lane == 0) atomicAdd(tw + 2, 1u);
-			seq = sq + 1;
-			if (t >= total_tk) return false;                   // (wave 0 requests nothing behind the end: every wave stops at this slot)
-			if (wave == 0) {
-				uint32_t* nw = &s_ctl[((sq + 1) & (TKR - 1)) * 3];
-				if (sq + 1 >= TKR) {                               // the slot still belongs to tile sq + 1 - TKR until every wave has read it
-					lds_wait(nw + 2, ENC_WAVES, 0, A.ctrl, lane);
-					if (lane == 0) lds_st(nw + 2, 0u);
-				}
-				if (lane == 0) pend = atomicAdd(A.ctrl, 1u);
-				pend_seq = sq + 1; pending = true;
-			}
-			if (setup(t, g)) return true;
-		}
-	};
-	// cursors over the wave's sequence of (segment, frame) items: `pf` = the item whose pixels are requested next, `nxt` = the
-	// item whose pixels are in flight (one ahead of the item being encoded)
-	struct Cursor { EncGeo g; int f; bool have; };
-	Cursor cur, nxt, pf;
-	auto advance = [&](Cursor& c) {                            // to the next item of the wave
-		if (c.f + 1 < c.g.f_hi) { c.f++; return; }
-		c.have = take_ticket(c.g);
-		c.f = c.have ? c.g.f_lo : 0;
-	};
-	pf.have = take_ticket(pf.g);
-	pf.f = pf.have ? pf.g.f_lo : 0;
-	uint32_t it = 0;
-	uint32_t ip[8];                                            // the GOP's I-frame entries of this block, two u16 per register
-	uint4 px[4];
-	nxt = pf;
-	if (pf.have) { load_frame(pf.g, A.pix + (size_t)pf.f * npx, px); advance(pf); }
-	bool have_prev = false;                                    // item it-1: segment, frame, bytes of this wave
-	uint32_t p_seg = 0, p_len = 0;
-	int p_f = 0;
-	uint8_t* const myslots = s_stage0 + (size_t)wave * 2 * WSLOT;
-
-	for (;;) {
-		// (L) the look-back window of item it-1 is requested first: it has landed when this item's look-ups have
-		unsigned long long pre = ST_PREFIX;                    // (L) the look-back window of item it-1: requested BEHIND this item's look-ups, see there
-		auto finish_prev = [&]() {                             // frame offset of item it-1, its prefix published, its bytes copied out
-			unsigned long long* st = A.status + (size_t)p_f * spf;
-			uint32_t excl = 0;
-#ifdef ABLW_NOSTATUS
-			if (false) {
-#else
-			if (p_seg != 0) {
+#ifdef AGMV_LAB_ENCODE_W
+#include "lab/k_encode_w.inc"   // the independent-wave form of k_encode (measured slower; profiles/r03/k_encode_experiments.txt)
 #endif
-				asm volatile("" : "+v"(pre));                  // (the select below stays here: ahead of this point it would wait for the window right behind its request)
-#ifdef ABLW_NOLOOKBACK
-				excl = 0;
-#else
-				excl = lookback_w(st, (int)p_seg, lane, A.ctrl, (int)p_seg - 1 - lane >= 0 ? pre : ST_PREFIX);
-#endif
-#ifdef ABLW_FEWSTORES
-				if (lane == 0 && wave == 0) st_store_untracked(st + p_seg, ST_PREFIX | (unsigned long long)(excl + p_len));
-#else
-				if (lane == 0) st_store_untracked(st + p_seg, ST_PREFIX | (unsigned long long)(excl + p_len));
-#endif
-			}
-			if (p_seg == spf - 1 && lane == 0) store32_untracked(A.sizes + p_f, excl + p_len);   // usize of the frame
-#ifndef ABLW_NOCOPY
-			if (p_len) wave_copy_own_u(myslots + ((it - 1) & 1) * WSLOT, A.out + (size_t)p_f * A.out_stride + excl, p_len, lane);
-#endif
-		};
-		cur = nxt;                                             // the item whose pixels are in px
-		if (!cur.have) {                                       // final drain: item it-1 is the last one
-#ifndef ABLW_NOSTATUS
-			if (have_prev && p_seg != 0) pre = st_load_raw(A.status + (size_t)p_f * spf, (int)p_seg - 1 - lane);
-#endif
-			if (have_prev) finish_prev();
-			break;
-		}
-		EncGeo& g = cur.g;
-		const int f = cur.f;
-		const bool new_tile = f == g.f_lo;
-		const bool is_i = ((A.first_fc + f) & 3u) == 0;
-		uint8_t* wslot = myslots + (it & 1) * WSLOT;           // free since this wave's copy-out of item it-2
-		uint8_t* scratch = wslot + 16;
-		if (new_tile) {
-			if (((A.first_fc + g.f_lo) & 3u) != 0) {           // GOP started in an earlier batch
-#pragma unroll
-				for (int r = 0; r < 4; r++) {
-					const uint2 q = *(const uint2*)(A.ientries_in + g.poff + r * A.w);
-					ip[2 * r] = q.x; ip[2 * r + 1] = q.y;
-				}
-			} else {
-#pragma unroll
-				for (int m = 0; m < 8; m++) ip[m] = 0;
-			}
-		}
-#if ENC_PRIO
-		__builtin_amdgcn_s_setprio(ENC_PRIO);
-#endif
-		// ---- (Q) colour -> entry through the exact table, lane = (block, row)
-		uint32_t eq[16];
-		const uint32_t pxv[16] = {px[0].x, px[0].y, px[0].z, px[0].w, px[1].x, px[1].y, px[1].z, px[1].w,
-		                          px[2].x, px[2].y, px[2].z, px[2].w, px[3].x, px[3].y, px[3].z, px[3].w};
-#pragma unroll
-		for (int k = 0; k < 16; k++) {
-			if (ENTRIES) eq[k] = pxv[k] & (M512 ? 0x1FFu : 0xFFu);
-			else eq[k] = (uint16_t)__builtin_amdgcn_raw_buffer_load_b16(lut_rs, lut_offset(pxv[k]), 0, ENC_LUTAUX);
-		}
-		// The status words bypass the caches (agent-scope atomics: a fabric round trip, 1-2 us) and a wave's memory counter
-		// retires in order: ahead of the look-ups, every wait for an entry would wait for that round trip first (measured:
-		// 1.05 against 0.7x ms per 256 frames).  Behind them it is the youngest load while the entries are awaited, and has
-		// this item's classification and emission to land in.
-		asm volatile("" ::: "memory");
-#if !defined(ABLW_NOSTATUS) && !defined(ABLW_NOLOOKBACK)
-		pre = st_load_raw(A.status + (size_t)p_f * spf, (int)p_seg - 1 - lane);   // unconditional (no item before this one: word 0 of frame 0, unused): under a branch the compiler could not count it and would drain it with the last look-up
-#endif
-		asm volatile("" ::: "memory");
-#if ENC_PRIO
-		__builtin_amdgcn_s_setprio(0);
-#endif
-		// [block][pixel] u16 table in the wave's scratch; a lane writes its row: 8 bytes at i*512 + lane*8
-#pragma unroll
-		for (int i = 0; i < 4; i++) {
-			uint2 q;
-			q.x = eq[i * 4 + 0] | (eq[i * 4 + 1] << 16);
-			q.y = eq[i * 4 + 2] | (eq[i * 4 + 3] << 16);
-			*(uint2*)(scratch + i * 512 + lane * 8) = q;
-		}
-		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-		__builtin_amdgcn_wave_barrier();
-		// ---- transpose: lane = block reads its 16 entries (32 contiguous bytes), kept PACKED two per register
-		uint32_t ep[8];
-		{
-			const uint4 lo = *(const uint4*)(scratch + lane * 32), hi = *(const uint4*)(scratch + lane * 32 + 16);
-			ep[0] = lo.x; ep[1] = lo.y; ep[2] = lo.z; ep[3] = lo.w; ep[4] = hi.x; ep[5] = hi.y; ep[6] = hi.z; ep[7] = hi.w;
-		}
-		post_ticket();                                         // (wave 0: the ticket it requested before these look-ups has landed with them)
-		// ---- (C) block tests: count1 = CompareIFrameBlock vs the top-left entry colour (src/agmv_encode.c:302-352),
-		// count2 = ComparePFrameBlock vs the I-frame entries (src/agmv_encode.c:240-300); one matrix bit per pixel
-		const uint32_t e0 = ep[0] & 0xffffu, row0 = e0 * MROW;
-		uint32_t acc1 = 0, acc2 = 0, nesc = 0;
-		if (is_i) block_tests<M512, false>(ep, ip, s_mtx, row0, acc1, acc2, nesc);
-		else block_tests<M512, true>(ep, ip, s_mtx, row0, acc1, acc2, nesc);
-		const uint32_t count1 = __popc(acc1), count2 = __popc(acc2);
-		const bool copy = !is_i && count2 >= COPY_COUNT;       // COPY has priority, :465
-		const bool fill = !copy && count1 >= FILL_COUNT;
-		uint32_t len;
-		if (copy) len = 1;
-		else if (fill) len = M512 ? (2u + ((e0 & 0xffu) >= 127u ? 1u : 0u)) : 2u;
-		else len = 17u + nesc;
-		if (!g.valid) len = 0;
-
-		if (is_i) {                                            // iframe_entries = img_entry, :626-630
-#pragma unroll
-			for (int m = 0; m < 8; m++) ip[m] = ep[m];
-			if (A.ientries_out && (uint32_t)f == A.last_iframe && g.valid) {
-#pragma unroll
-				for (int r = 0; r < 4; r++) {
-					uint2 q;
-					q.x = ep[2 * r]; q.y = ep[2 * r + 1];
-					*(uint2*)(A.ientries_out + g.poff + r * A.w) = q;
-				}
-			}
-		}
-		// ---- byte offsets inside the wave; the segment's aggregate goes to the status row at once
-		const uint32_t incl = wave_incl_scan(len, lane);
-		const uint32_t wtot = __builtin_amdgcn_readlane(incl, 63);
-#ifndef ABLW_NOSTATUS
-#ifdef ABLW_FEWSTORES
-		if (lane == 0) st_store_untracked(A.status + (size_t)f * spf + g.tile, (g.tile == 0 || wave != 0 ? ST_PREFIX : ST_AGG) | wtot);   // (ablation: every word reads as a prefix, so nobody waits for the prefix stores that are left out)
-#else
-		if (lane == 0) st_store_untracked(A.status + (size_t)f * spf + g.tile, (g.tile == 0 ? ST_PREFIX : ST_AGG) | wtot);
-#endif
-#endif
-		// ---- (E) emit this block's bytes into the wave's stage slot (see k_encode above for the byte-pair trick)
-		if (g.valid) {
-			uint8_t* sp = wslot + 16 + incl - len;
-			if (!copy && !fill) {
-				if (M512) {
-					uint32_t n = 0;                                // escape bytes so far
-#pragma unroll
-					for (int m = 0; m < 8; m++) {
-						const uint32_t p = ep[m], idx2 = p & 0x00FF00FFu;
-						const u16x2 c2 = __builtin_elementwise_min(__builtin_bit_cast(u16x2, idx2), __builtin_bit_cast(u16x2, 0x007F007Fu));
-						const uint32_t code2 = ((p >> 1) & 0x00800080u) | __builtin_bit_cast(uint32_t, c2);   // :395-401
-						const uint32_t w = __builtin_amdgcn_perm(code2, p, 0x02060004u);   // code_lo, idx_lo, code_hi, idx_hi
-						const uint32_t e2 = idx2 + 0x00810081u;    // bit 8 / bit 24: index >= 127
-						*(u16u*)(sp + n + (1 + 2 * m)) = (uint16_t)w;
-						n += (e2 >> 8) & 1u;
-						*(u16u*)(sp + n + (2 + 2 * m)) = (uint16_t)(w >> 16);
-						n += e2 >> 24;
-					}
-				} else {
-#pragma unroll
-					for (int m = 0; m < 4; m++)                    // :428-429
-						*(u32u*)(sp + 1 + 4 * m) = __builtin_amdgcn_perm(ep[2 * m + 1], ep[2 * m], 0x06040200u);
-				}
-			} else if (fill) {
-				if (M512) {
-					const uint32_t idx = e0 & 0xffu, p7 = (e0 >> 1) & 0x80u;
-					*(u16u*)(sp + 1) = (uint16_t)(p7 | (idx < 127u ? idx : 127u) | (idx << 8));   // :382-388
-				} else {
-					sp[1] = (uint8_t)e0;                           // :421
-				}
-			}
-			asm volatile("" ::: "memory");
-			sp[0] = copy ? COPY_FLAG : (fill ? FILL_FLAG : NORMAL_FLAG);
-		}
-		if (have_prev) finish_prev();
-		// ---- the next item's pixels, into the registers this item's pixels left
-		asm volatile("" ::: "memory");
-		have_prev = true; p_seg = g.tile; p_f = f; p_len = wtot;
-		it++;
-		nxt = pf;
-		if (pf.have) { load_frame(pf.g, A.pix + (size_t)pf.f * npx, px); advance(pf); }
-	}
-}
 
 // ----------------------------------------------------------------------------------------------
 // decode side
@@ -1873,9 +1428,7 @@ __device__ __forceinline__ void fp_walk_region(const FpArgs& A, uint32_t* s_b, u
 			uint32_t len1 = isC ? 1u : 2u + ((M512 && ((two >> 8) & 0x7Fu) == 127u) ? 1u : 0u);   // length of the block at q
 			uint32_t nrun = 1, qm = 1;                             // blocks taken; their nodes as a mask from q
 			if (isC && rc > 1u) { nrun = rc; qm = (1u << rc) - 1u; }
-#ifndef FP_NOFILLRUN
 			if (!isC && !isN && rl > 1u) { nrun = rl; qm = ((1u << (2u * rl)) - 1u) & 0x55555555u; }
-#endif
 			// NORMAL lengths (16 dependent steps), for all the lanes that wait at one (FP_NBATCH: or only once enough of them do)
 			const unsigned long long pm = __ballot(go && isN), am = __ballot(go && !isN);
 			const bool doN = pm != 0 && (am == 0 || __popcll(pm) >= FP_NBATCH);
@@ -2304,13 +1857,9 @@ __device__ __forceinline__ void store_block(uint32_t* frame, uint32_t poff, uint
 	for (int r = 0; r < 4; r++) {
 		uint4 q;
 		q.x = v[r * 4 + 0]; q.y = v[r * 4 + 1]; q.z = v[r * 4 + 2]; q.w = v[r * 4 + 3];
-#ifdef DEC_TSTORE
-		*(uint4*)(frame + poff + r * w) = q;
-#else
 		// written once, read by nobody on the device: non-temporal (measured 0.474 -> 0.386 ms per 256 x 1080p frames)
 		typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 		__builtin_nontemporal_store((u32x4){q.x, q.y, q.z, q.w}, (u32x4*)(frame + poff + r * w));
-#endif
 	}
 }
 
@@ -2811,6 +2360,37 @@ __global__ __launch_bounds__(64) void k_within2_count(const uint32_t* __restrict
 // ----------------------------------------------------------------------------------------------
 // C-ABI
 // ----------------------------------------------------------------------------------------------
+// ----------------------------------------------------------------------------------------------
+// Palette tables (colour -> entry table, +-2 bit matrix, palette) are read-only once built and identical for every
+// context that holds the same palette on the same device -- the sequence drivers open two worker contexts per device
+// besides the caller's.  They are shared: one 512 MiB allocation and one 2 ms table build per (device, palette).
+// ----------------------------------------------------------------------------------------------
+struct lut_share {
+	int device, mode512, refs;
+	uint32_t pal[512];
+	uint16_t* d_lut;
+	uint32_t* d_mtx;
+	uint32_t* d_pal;
+	hipEvent_t built;               // recorded behind the build kernels; a context on another stream waits for it
+	lut_share* next;
+};
+static pthread_mutex_t g_lut_mu = PTHREAD_MUTEX_INITIALIZER;
+static lut_share* g_luts = nullptr;
+
+static void lut_release(lut_share* sh)                        // (device of the share is current)
+{
+	if (!sh) return;
+	pthread_mutex_lock(&g_lut_mu);
+	if (--sh->refs == 0) {
+		for (lut_share** pp = &g_luts; *pp; pp = &(*pp)->next)
+			if (*pp == sh) { *pp = sh->next; break; }
+		(void)hipFree(sh->d_lut); (void)hipFree(sh->d_mtx); (void)hipFree(sh->d_pal);
+		if (sh->built) (void)hipEventDestroy(sh->built);
+		free(sh);
+	}
+	pthread_mutex_unlock(&g_lut_mu);
+}
+
 extern "C" int agmv_hip_device_count(void)
 {
 	int n = 0;
@@ -2818,6 +2398,7 @@ extern "C" int agmv_hip_device_count(void)
 	return n;
 }
 
+extern "C" void agmv_hip_destroy(agmv_hip_ctx* c);
 extern "C" agmv_hip_ctx* agmv_hip_create(int device)
 {
 	int n = 0;
@@ -2833,13 +2414,16 @@ extern "C" agmv_hip_ctx* agmv_hip_create(int device)
 	}
 	CKP(hipSetDevice(device));
 	agmv_hip_ctx* c = (agmv_hip_ctx*)calloc(1, sizeof(*c));
+	if (!c) { snprintf(g_err, sizeof(g_err), "agmv_hip: out of host memory"); return nullptr; }
 	c->device = device;
-	CKP(hipMalloc(&c->d_lut, (size_t)LUT_ENTRIES * sizeof(uint16_t)));
-	CKP(hipMalloc(&c->d_mtx, 512 * MROW * sizeof(uint32_t)));
-	CKP(hipMalloc(&c->d_pal, 512 * sizeof(uint32_t)));
-	CKP(hipMalloc(&c->d_ctrl, CTRL_BYTES));
 	hipDeviceProp_t prop;
-	CKP(hipGetDeviceProperties(&prop, device));
+	hipError_t e2 = hipMalloc(&c->d_ctrl, CTRL_BYTES);
+	if (e2 == hipSuccess) e2 = hipGetDeviceProperties(&prop, device);
+	if (e2 != hipSuccess) {                                    // nothing half-built is left behind
+		fail("agmv_hip_create", e2, __LINE__);
+		agmv_hip_destroy(c);
+		return nullptr;
+	}
 	c->n_cu = prop.multiProcessorCount;
 	// persistent grid of k_encode = the workgroups that are resident at once (2 per CU: 69 KB of LDS each)
 	{
@@ -2857,7 +2441,8 @@ extern "C" void agmv_hip_destroy(agmv_hip_ctx* c)
 {
 	if (!c) return;
 	(void)hipSetDevice(c->device);
-	(void)hipFree(c->d_lut); (void)hipFree(c->d_mtx); (void)hipFree(c->d_pal); (void)hipFree(c->d_ctrl);
+	lut_release(c->share);
+	(void)hipFree(c->d_ctrl);
 	(void)hipFree(c->d_status); (void)hipFree(c->d_dirty); (void)hipFree(c->d_parse_ws); (void)hipFree(c->d_fp_ws); (void)hipFree(c->d_ient_tmp);
 	(void)hipFree(c->d_nent_own); (void)hipFree(c->d_nn_pal); (void)hipFree(c->d_nn_pix); (void)hipFree(c->d_nn_ent);
 	if (c->ev_enc) (void)hipEventDestroy(c->ev_enc);
@@ -2908,14 +2493,52 @@ extern "C" int agmv_hip_set_palette(agmv_hip_ctx* c, const uint32_t p0[256], con
 	uint32_t pal[512];
 	memcpy(pal, p0, 1024);
 	if (p1) memcpy(pal + 256, p1, 1024); else memset(pal + 256, 0, 1024);
-	CK(hipMemcpyAsync(c->d_pal, pal, sizeof(pal), hipMemcpyHostToDevice, s));
-	CK(hipStreamSynchronize(s));                              // pal[] is a stack buffer
-	hipLaunchKernelGGL(k_lut_build, dim3(LUT_COLOURS / 256), dim3(256), 0, s, c->d_pal, mode512 ? 1 : 0, c->d_lut);
-	CK(hipGetLastError());
-	hipLaunchKernelGGL(k_mtx_build, dim3((512 * MROW + 255) / 256), dim3(256), 0, s, c->d_pal, c->d_mtx);
-	CK(hipGetLastError());
-	c->mode512 = mode512 ? 1 : 0;
+	mode512 = mode512 ? 1 : 0;
+	pthread_mutex_lock(&g_lut_mu);
+	lut_share* sh = nullptr;
+	for (lut_share* q = g_luts; q; q = q->next)
+		if (q->device == c->device && q->mode512 == mode512 && memcmp(q->pal, pal, sizeof(pal)) == 0) { sh = q; break; }
+	int rc = 0;
+	if (sh) sh->refs++;
+	else {
+		sh = (lut_share*)calloc(1, sizeof(*sh));
+		hipError_t e = sh ? hipSuccess : hipErrorOutOfMemory;
+		if (e == hipSuccess) e = hipMalloc(&sh->d_lut, (size_t)LUT_ENTRIES * sizeof(uint16_t));
+		if (e == hipSuccess) e = hipMalloc(&sh->d_mtx, 512 * MROW * sizeof(uint32_t));
+		if (e == hipSuccess) e = hipMalloc(&sh->d_pal, 512 * sizeof(uint32_t));
+		if (e == hipSuccess) e = hipEventCreateWithFlags(&sh->built, hipEventDisableTiming);
+		if (e == hipSuccess) e = hipMemcpyAsync(sh->d_pal, pal, sizeof(pal), hipMemcpyHostToDevice, s);
+		if (e == hipSuccess) e = hipStreamSynchronize(s);       // pal[] is a stack buffer
+		if (e == hipSuccess) {
+			hipLaunchKernelGGL(k_lut_build, dim3(LUT_COLOURS / 256), dim3(256), 0, s, sh->d_pal, mode512, sh->d_lut);
+			e = hipGetLastError();
+		}
+		if (e == hipSuccess) {
+			hipLaunchKernelGGL(k_mtx_build, dim3((512 * MROW + 255) / 256), dim3(256), 0, s, sh->d_pal, sh->d_mtx);
+			e = hipGetLastError();
+		}
+		if (e == hipSuccess) e = hipEventRecord(sh->built, s);
+		if (e != hipSuccess) {
+			rc = fail("agmv_hip_set_palette", e, __LINE__);
+			if (sh) { (void)hipFree(sh->d_lut); (void)hipFree(sh->d_mtx); (void)hipFree(sh->d_pal); if (sh->built) (void)hipEventDestroy(sh->built); free(sh); }
+			sh = nullptr;
+		} else {
+			sh->device = c->device; sh->mode512 = mode512; sh->refs = 1;
+			memcpy(sh->pal, pal, sizeof(pal));
+			sh->next = g_luts; g_luts = sh;
+		}
+	}
+	pthread_mutex_unlock(&g_lut_mu);
+	if (rc) return rc;
+	if (hipStreamWaitEvent(s, sh->built, 0) != hipSuccess) { lut_release(sh); return fail("hipStreamWaitEvent", hipErrorUnknown, __LINE__); }   // built on another context's stream?
+	lut_share* old_sh = c->share;
+	c->share = sh; c->d_lut = sh->d_lut; c->d_mtx = sh->d_mtx; c->d_pal = sh->d_pal;
+	c->mode512 = mode512;
 	c->have_palette = 1;
+	if (old_sh) {                                             // work of this context still in flight may read the old tables
+		CK(hipDeviceSynchronize());
+		lut_release(old_sh);
+	}
 	return 0;
 }
 
@@ -2959,10 +2582,13 @@ static int encode_dev(agmv_hip_ctx* c, const uint32_t* d_pix, uint32_t n_frames,
 	A.pix = d_pix; A.out = d_out; A.sizes = d_sizes; A.lut = c->d_lut; A.mtx = c->d_mtx; A.ientries_in = d_ientries; A.ientries_out = d_ientries;
 	A.out_stride = out_stride;
 	A.n_frames = n_frames; A.w = w; A.h = h; A.bw = w / 4; A.nblk = (w / 4) * (h / 4);
-	// two forms of the kernel: the workgroup dataflow (k_encode, default) and independent waves (k_encode_w; AGMV_ENC_KERNEL=w)
-	const char* ek = getenv("AGMV_ENC_KERNEL");
+#ifdef AGMV_LAB_ENCODE_W
+	const char* ek = getenv("AGMV_ENC_KERNEL");                // lab build only: the independent-wave form (lab/k_encode_w.inc)
 	const bool wform = ek && strcmp(ek, "w") == 0;
-	A.tpf = wform ? (A.nblk + WBLK - 1) / WBLK : (A.nblk + ENC_T - 1) / ENC_T;   // segments of 64 blocks / tiles of ENC_T blocks per frame
+#else
+	constexpr bool wform = false;
+#endif
+	A.tpf = wform ? (A.nblk + WBLK - 1) / WBLK : (A.nblk + ENC_T - 1) / ENC_T;   // tiles of ENC_T blocks per frame
 	A.first_fc = first_fc; A.phase = first_fc & 3u;
 	A.n_groups = (n_frames + A.phase + 3) / 4;
 	A.total_tiles = A.n_groups * A.tpf;
@@ -3003,11 +2629,16 @@ static int encode_dev(agmv_hip_ctx* c, const uint32_t* d_pix, uint32_t n_frames,
 	uint32_t grid = (uint32_t)c->enc_grid;
 	const uint32_t work = wform ? (A.total_tiles + ENC_WAVES - 1) / ENC_WAVES : A.total_tiles;
 	if (grid > work) grid = work;
-	const size_t lds = (size_t)(c->mode512 ? 512 : 256) * MROW * 4 + (wform ? ENCW_LDS_EXTRA : ENC_LDS_EXTRA);
-	void (*kern)(EncArgs) = wform ? (c->mode512 ? (entries ? k_encode_w<true, true> : k_encode_w<true, false>)
-	                                            : (entries ? k_encode_w<false, true> : k_encode_w<false, false>))
-	                              : (c->mode512 ? (entries ? k_encode<true, true> : k_encode<true, false>)
-	                                            : (entries ? k_encode<false, true> : k_encode<false, false>));
+	size_t lds = (size_t)(c->mode512 ? 512 : 256) * MROW * 4 + ENC_LDS_EXTRA;
+	void (*kern)(EncArgs) = c->mode512 ? (entries ? k_encode<true, true> : k_encode<true, false>)
+	                                   : (entries ? k_encode<false, true> : k_encode<false, false>);
+#ifdef AGMV_LAB_ENCODE_W
+	if (wform) {
+		lds = (size_t)(c->mode512 ? 512 : 256) * MROW * 4 + ENCW_LDS_EXTRA;
+		kern = c->mode512 ? (entries ? k_encode_w<true, true> : k_encode_w<true, false>)
+		                  : (entries ? k_encode_w<false, true> : k_encode_w<false, false>);
+	}
+#endif
 	CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
 	ev_mark(c, 0, s);
 	hipLaunchKernelGGL(kern, dim3(grid), dim3(ENC_T), lds, s, A);

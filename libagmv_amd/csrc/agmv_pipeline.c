@@ -29,6 +29,11 @@
 
 #include <time.h>
 static double now_s(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec + 1e-9 * t.tv_nsec; }
+/* host allocations of the drivers: the void encoders have no error channel (reference src/agmv_encode.c:529), so a failed
+   allocation ends the process with a message instead of a NULL dereference in some pool thread */
+static void* xmalloc(size_t n) { void* p = malloc(n ? n : 1); if (!p) agmv_die("out of host memory"); return p; }
+static void* xcalloc(size_t n, size_t m) { void* p = calloc(n ? n : 1, m ? m : 1); if (!p) agmv_die("out of host memory"); return p; }
+
 static int tracing(void) { static int v = -1; if (v < 0) v = getenv("AGMV_TRACE") != NULL; return v; }
 #define TRACE(...) do { if (tracing()) fprintf(stderr, "agmv trace: " __VA_ARGS__); } while (0)
 
@@ -65,20 +70,23 @@ static void* pool_main(void* arg)
 
 agmv_pool* agmv_pool_start(unsigned threads)
 {
-	agmv_pool* p = (agmv_pool*)calloc(1, sizeof(*p));
+	agmv_pool* p = (agmv_pool*)xcalloc(1, sizeof(*p));
 	unsigned i;
 	if (threads < 1) threads = 1;
 	if (threads > 64) threads = 64;
 	pthread_mutex_init(&p->mu, NULL);
 	pthread_cond_init(&p->cv, NULL);
-	p->nth = threads;
-	for (i = 0; i < threads; i++) pthread_create(&p->th[i], NULL, pool_main, p);
+	p->nth = 0;
+	for (i = 0; i < threads; i++) {                            /* only threads that exist are joined later */
+		if (pthread_create(&p->th[p->nth], NULL, pool_main, p) == 0) p->nth++;
+	}
+	if (p->nth == 0) agmv_die("cannot start a host worker thread");
 	return p;
 }
 
 void agmv_pool_submit(agmv_pool* p, void (*fn)(void*), void* arg)
 {
-	task* t = (task*)malloc(sizeof(*t));
+	task* t = (task*)xmalloc(sizeof(*t));
 	t->fn = fn; t->arg = arg; t->next = NULL;
 	pthread_mutex_lock(&p->mu);
 	if (p->tail) p->tail->next = t; else p->head = t;
@@ -257,7 +265,7 @@ static void* eworker_main(void* p)
 			}
 		}
 		if (b->first_fc & 3u) {                            /* the batch completes a GOP the caller began: its I-frame entries */
-			uint16_t* e = (uint16_t*)malloc(s->npx * 2);
+			uint16_t* e = (uint16_t*)xmalloc(s->npx * 2);
 			size_t i;
 			for (i = 0; i < s->npx; i++) e[i] = (uint16_t)((s->a->iframe_entries[i].pal_num & 1u) << 8 | s->a->iframe_entries[i].index);
 			if (agmv_hip_stream_sync(wk->ctx, wk->stream) || agmv_hip_memcpy_async(wk->ctx, wk->d_ient, e, s->npx * 2, 0, wk->stream) ||
@@ -296,7 +304,7 @@ static void prepare_batch(agmv_seq* s, ebatch* b)
 	size_t need = 0, coff = 0;
 	unsigned k;
 	for (k = 0; k < b->n; k++) need += (size_t)b->sizes[k] * (s->lz77 ? 4 : 2) + 64;
-	if (need > b->comp_cap) { free(b->comp); b->comp_cap = need + need / 4; b->comp = (u8*)malloc(b->comp_cap); }
+	if (need > b->comp_cap) { free(b->comp); b->comp_cap = need + need / 4; b->comp = (u8*)xmalloc(b->comp_cap); }
 	for (k = 0; k < b->n; k++) {
 		u8* raw = b->h_bits + b->boff[k];
 		const size_t n = b->sizes[k];
@@ -309,7 +317,7 @@ static void prepare_batch(agmv_seq* s, ebatch* b)
 	b->lz_left = b->n;
 	pthread_mutex_unlock(&s->mu);
 	for (k = 0; k < b->n; k++) {
-		lzarg* za = (lzarg*)malloc(sizeof(*za));
+		lzarg* za = (lzarg*)xmalloc(sizeof(*za));
 		za->s = s; za->b = b; za->k = k;
 		agmv_pool_submit(s->pool, lz_task, za);
 	}
@@ -390,7 +398,7 @@ static void submit_batch(agmv_seq* s)
 	for (k = 0; k < b->n; k++) {
 		int which;
 		for (which = 0; which < (b->srcB[k] < 0 ? 1 : 2); which++) {
-			loadarg* la = (loadarg*)malloc(sizeof(*la));
+			loadarg* la = (loadarg*)xmalloc(sizeof(*la));
 			la->s = s; la->b = b; la->k = k; la->which = which;
 			agmv_pool_submit(s->pool, load_task, la);
 		}
@@ -401,13 +409,17 @@ static void submit_batch(agmv_seq* s)
 agmv_seq* agmv_seq_open(AGMV* a, FILE* file, const char* dir, const char* base, int scale_w, int scale_h, int mode512, int lz77,
                         int audio_chunks, int use_interp, unsigned cap, unsigned devices, unsigned threads, const uint32_t pal[512])
 {
-	agmv_seq* s = (agmv_seq*)calloc(1, sizeof(*s));
+	agmv_seq* s = (agmv_seq*)xcalloc(1, sizeof(*s));
 	unsigned i, ndev = (unsigned)agmv_hip_device_count();
 	const double t0 = now_s();
 	double t1;
 	if (ndev < 1) agmv_die("cannot open the GPU");
 	if (devices < 1) devices = 1;
-	if (devices > ndev) devices = ndev;
+	{	/* AGMV_DEVICES_OVERSUBSCRIBE=1: more "devices" than cards -- worker pair d runs on card d % ndev.  The round-robin of
+		   batches over devices, the in-order chunk writer and the per-device tables are then exercised on a one-GPU box. */
+		const char* ov = getenv("AGMV_DEVICES_OVERSUBSCRIBE");
+		if (devices > ndev && !(ov && atoi(ov) != 0)) devices = ndev;
+	}
 	s->a = a; s->file = file; s->dir = dir; s->base = base; s->scale_w = scale_w; s->scale_h = scale_h;
 	s->audio_chunks = audio_chunks; s->mode512 = mode512; s->lz77 = lz77; s->use_b = use_interp;
 	s->w = (uint32_t)AGMV_GetWidth(a); s->h = (uint32_t)AGMV_GetHeight(a);
@@ -420,25 +432,25 @@ agmv_seq* agmv_seq_open(AGMV* a, FILE* file, const char* dir, const char* base, 
 	pthread_cond_init(&s->cv, NULL);
 	s->pool = agmv_pool_start(threads);
 	s->persist_len = s->stride + 64;
-	s->persist = (u8*)calloc(s->persist_len, 1);
-	s->slot = (ebatch*)calloc(s->nslots, sizeof(ebatch));
+	s->persist = (u8*)xcalloc(s->persist_len, 1);
+	s->slot = (ebatch*)xcalloc(s->nslots, sizeof(ebatch));
 	for (i = 0; i < s->nslots; i++) {
 		ebatch* b = &s->slot[i];
 		b->id = ~0u;
-		b->srcA = (long*)malloc(sizeof(long) * s->cap); b->srcB = (long*)malloc(sizeof(long) * s->cap);
-		b->boff = (size_t*)malloc(sizeof(size_t) * s->cap);
-		b->jobs = (lzjob*)calloc(s->cap, sizeof(lzjob));
+		b->srcA = (long*)xmalloc(sizeof(long) * s->cap); b->srcB = (long*)xmalloc(sizeof(long) * s->cap);
+		b->boff = (size_t*)xmalloc(sizeof(size_t) * s->cap);
+		b->jobs = (lzjob*)xcalloc(s->cap, sizeof(lzjob));
 		b->h_pix = (uint32_t*)agmv_hip_host_alloc(s->per * 4 * s->cap);
 		b->sizes = (uint32_t*)agmv_hip_host_alloc(4 * (size_t)s->cap + 64);
 		if (!b->h_pix || !b->sizes) agmv_die("pinned allocation");
 	}
 	t1 = now_s();
 	TRACE("seq_open: pool + %u pinned slots of %.1f MB in %.3f s\n", s->nslots, s->per * 4.0 * s->cap / 1e6, t1 - t0);
-	s->wk = (eworker*)calloc(s->nworkers, sizeof(eworker));
+	s->wk = (eworker*)xcalloc(s->nworkers, sizeof(eworker));
 	for (i = 0; i < s->nworkers; i++) {
 		eworker* wk = &s->wk[i];
 		wk->s = s; wk->idx = i;
-		wk->ctx = agmv_hip_create((int)(i % devices));
+		wk->ctx = agmv_hip_create((int)((i % devices) % ndev));
 		if (!wk->ctx) agmv_die("cannot open the GPU");
 		if (agmv_hip_set_palette(wk->ctx, pal, pal + 256, mode512, NULL) || agmv_hip_sync()) agmv_die("palette upload");
 		wk->stream = agmv_hip_stream_create(wk->ctx);
@@ -450,7 +462,7 @@ agmv_seq* agmv_seq_open(AGMV* a, FILE* file, const char* dir, const char* base, 
 		wk->d_tmp[1] = use_interp ? (uint32_t*)agmv_hip_malloc_on(wk->ctx, s->npx * 4) : NULL;
 		if (!wk->stream || !wk->d_frames || !wk->d_out || !wk->d_sizes || !wk->d_ient || (use_interp && (!wk->d_tmp[0] || !wk->d_tmp[1])))
 			agmv_die("device allocation");
-		pthread_create(&wk->th, NULL, eworker_main, wk);
+		if (pthread_create(&wk->th, NULL, eworker_main, wk)) agmv_die("cannot start a GPU worker thread");
 	}
 	TRACE("seq_open: %u GPU workers (context + table + buffers) in %.3f s\n", s->nworkers, now_s() - t1);
 	s->t_open = now_s();
@@ -531,9 +543,14 @@ static void hist_load_task(void* p)
 void agmv_histogram_frames(agmv_hip_ctx* ctx, const char* dir, const char* base, u32 start, u32 end, u32 size, int quality,
                            unsigned threads, uint32_t* hist /* 2^19 bins */)
 {
-	const u32 n = end - start + 1;
+	const u32 n = end >= start ? end - start + 1 : 0;
 	const double t0 = now_s();
-	uint32_t *d_hist = (uint32_t*)agmv_hip_malloc_on(ctx, 4u << 19), *d_pix;
+	uint32_t *d_hist, *d_pix;
+	if (n == 0) {                                              /* the reference's `for (i = start; i <= end; i++)` does not run (src/agmv_encode.c:2371-2397) */
+		memset(hist, 0, 4u << 19);
+		return;
+	}
+	d_hist = (uint32_t*)agmv_hip_malloc_on(ctx, 4u << 19);
 	void* stream = agmv_hip_stream_create(ctx);
 	agmv_pool* pool = agmv_pool_start(threads);
 	hctx c;
@@ -541,13 +558,13 @@ void agmv_histogram_frames(agmv_hip_ctx* ctx, const char* dir, const char* base,
 	memset(&c, 0, sizeof(c));
 	pthread_mutex_init(&c.mu, NULL);
 	pthread_cond_init(&c.cv, NULL);
-	c.fr = (hframe*)calloc(n, sizeof(hframe)); c.dir = dir; c.base = base; c.start = start;
+	c.fr = (hframe*)xcalloc(n, sizeof(hframe)); c.dir = dir; c.base = base; c.start = start;
 	/* a ring of pinned frames, parsed ahead of the GPU by the host cores; only the first `size` pixels of a frame count
 	   (the reference histograms img[0 .. width*height) of the size it was told, src/agmv_encode.c:2390-2394) */
 	c.window = threads + 2;
 	if (c.window > n) c.window = n;
 	c.ring_px = size;
-	c.ring = (uint32_t**)calloc(c.window, sizeof(uint32_t*));
+	c.ring = (uint32_t**)xcalloc(c.window, sizeof(uint32_t*));
 	for (i = 0; i < c.window; i++) { c.ring[i] = (uint32_t*)agmv_hip_host_alloc(c.ring_px * 4); if (!c.ring[i]) agmv_die("pinned allocation"); }
 	d_pix = (uint32_t*)agmv_hip_malloc_on(ctx, c.ring_px * 4);
 	if (!d_hist || !d_pix || !stream) agmv_die("device allocation");
@@ -556,7 +573,7 @@ void agmv_histogram_frames(agmv_hip_ctx* ctx, const char* dir, const char* base,
 		hframe* f = &c.fr[i];
 		size_t px;
 		while (issued < n && issued < i + c.window) {      /* slot issued % window was consumed with frame issued - window */
-			harg* ha = (harg*)malloc(sizeof(*ha));
+			harg* ha = (harg*)xmalloc(sizeof(*ha));
 			ha->c = &c; ha->i = issued++;
 			agmv_pool_submit(pool, hist_load_task, ha);
 		}
@@ -605,7 +622,7 @@ typedef struct dpipe {
 	int closing, failed;
 	agmv_pool* pool;
 	pthread_t th;
-	uint8_t* d_bits; uint32_t *d_bpos, *d_off, *d_nent, *d_out[2], *d_iframe;
+	uint8_t* d_bits; uint32_t *d_bpos, *d_nent, *d_out[2], *d_iframe;
 } dpipe;
 
 typedef struct savearg { dpipe* d; dbatch* b; unsigned k; } savearg;
@@ -640,9 +657,8 @@ static void* dworker_main(void* p)
 		pthread_mutex_unlock(&d->mu);
 		if (agmv_hip_memcpy_async(d->ctx, d->d_bits, b->h_slab, d->stride * b->n, 0, d->stream) ||
 		    agmv_hip_memcpy_async(d->ctx, d->d_bpos, b->h_bpos, 4 * (size_t)b->n, 0, d->stream) ||
-		    agmv_hip_parse_frames_dev(d->ctx, d->d_bits, d->stride, d->d_bpos, b->n, d->w, d->h, d->d_off, d->d_nent, d->stream) ||
-		    agmv_hip_decode_frames_dev(d->ctx, d->d_bits, d->stride, d->d_bpos, d->d_off, d->d_nent, b->n, d->w, d->h, b->first, out, prev,
-		                               have_state ? d->d_iframe : NULL, d->stream))
+		    agmv_hip_decode_bitstreams_dev(d->ctx, d->d_bits, d->stride, d->d_bpos, b->n, d->w, d->h, b->first, d->d_nent, out, prev,
+		                                   have_state ? d->d_iframe : NULL, d->stream))
 			goto fail;
 		/* decoder state for the next batch stays on the device: img_data = the last frame (read in place from this batch's
 		   output), iframe = the last I-frame of the batch (src/agmv_decode.c:401-405) */
@@ -658,7 +674,7 @@ static void* dworker_main(void* p)
 		pthread_cond_broadcast(&d->cv);
 		pthread_mutex_unlock(&d->mu);
 		for (k = 0; k < b->n; k++) {
-			savearg* sa = (savearg*)malloc(sizeof(*sa));
+			savearg* sa = (savearg*)xmalloc(sizeof(*sa));
 			sa->d = d; sa->b = b; sa->k = k;
 			agmv_pool_submit(d->pool, save_task, sa);
 		}
@@ -732,15 +748,15 @@ int agmv_decode_stream(agmv_hip_ctx* ctx, const u8* file, size_t len, size_t pos
 	pthread_mutex_init(&d.mu, NULL);
 	pthread_cond_init(&d.cv, NULL);
 	d.slot = (dbatch*)calloc(d.nslots, sizeof(dbatch));
+	if (!d.slot) { d.nslots = 0; rc = MEMORY_CORRUPTION_ERR; goto out; }
 	d.stream = agmv_hip_stream_create(ctx);
 	d.d_bits = (uint8_t*)agmv_hip_malloc_on(ctx, d.stride * d.cap);
 	d.d_bpos = (uint32_t*)agmv_hip_malloc_on(ctx, 4 * (size_t)d.cap);
-	d.d_off = (uint32_t*)agmv_hip_malloc_on(ctx, 4 * (npx / 16) * d.cap);
 	d.d_nent = (uint32_t*)agmv_hip_malloc_on(ctx, 4 * (size_t)d.cap);
 	d.d_out[0] = (uint32_t*)agmv_hip_malloc_on(ctx, npx * 4 * d.cap);
 	d.d_out[1] = (uint32_t*)agmv_hip_malloc_on(ctx, npx * 4 * d.cap);
 	d.d_iframe = (uint32_t*)agmv_hip_malloc_on(ctx, npx * 4);
-	if (!persist || !d.stream || !d.d_bits || !d.d_bpos || !d.d_off || !d.d_nent || !d.d_out[0] || !d.d_out[1] || !d.d_iframe) { rc = MEMORY_CORRUPTION_ERR; goto out; }
+	if (!persist || !d.stream || !d.d_bits || !d.d_bpos || !d.d_nent || !d.d_out[0] || !d.d_out[1] || !d.d_iframe) { rc = MEMORY_CORRUPTION_ERR; goto out; }
 	for (i = 0; i < d.nslots; i++) {
 		d.slot[i].h_slab = (u8*)agmv_hip_host_alloc(d.stride * d.cap);
 		d.slot[i].h_bpos = (uint32_t*)agmv_hip_host_alloc(4 * (size_t)d.cap + 64);
@@ -748,7 +764,11 @@ int agmv_decode_stream(agmv_hip_ctx* ctx, const u8* file, size_t len, size_t pos
 		if (!d.slot[i].h_slab || !d.slot[i].h_bpos || !d.slot[i].h_out) { rc = MEMORY_CORRUPTION_ERR; goto out; }
 	}
 	d.pool = agmv_pool_start(threads);
-	pthread_create(&d.th, NULL, dworker_main, &d);
+	if (pthread_create(&d.th, NULL, dworker_main, &d)) {       /* no worker: nothing to join, nothing would ever consume a batch */
+		agmv_pool_stop(d.pool);
+		rc = MEMORY_CORRUPTION_ERR;
+		goto out;
+	}
 	while (done < nframes) {
 		dbatch* b = &d.slot[id % d.nslots];
 		unsigned n = 0;
@@ -811,7 +831,7 @@ int agmv_decode_stream(agmv_hip_ctx* ctx, const u8* file, size_t len, size_t pos
 	if (d.failed) rc = MEMORY_CORRUPTION_ERR;
 out:
 	for (i = 0; i < d.nslots; i++) { agmv_hip_host_free(d.slot[i].h_slab); agmv_hip_host_free(d.slot[i].h_bpos); agmv_hip_host_free(d.slot[i].h_out); }
-	agmv_hip_free_on(ctx, d.d_bits); agmv_hip_free_on(ctx, d.d_bpos); agmv_hip_free_on(ctx, d.d_off); agmv_hip_free_on(ctx, d.d_nent);
+	agmv_hip_free_on(ctx, d.d_bits); agmv_hip_free_on(ctx, d.d_bpos); agmv_hip_free_on(ctx, d.d_nent);
 	agmv_hip_free_on(ctx, d.d_out[0]); agmv_hip_free_on(ctx, d.d_out[1]); agmv_hip_free_on(ctx, d.d_iframe);
 	agmv_hip_stream_destroy(ctx, d.stream);
 	free(d.slot); free(persist);

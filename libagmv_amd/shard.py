@@ -42,13 +42,49 @@ def pack_frames(out, sizes):
     return torch.cat([out[f, :sz[f]] for f in range(len(sz))])
 
 
+def _stages(dist, t):
+    """gloo moves host memory only: a device tensor goes through a host copy there (tests, and bench.py --backend gloo, which
+    rehearse the multi-rank path on one card).  With "nccl" (= RCCL) device tensors travel as they are, over xGMI."""
+    return t.is_cuda and dist.get_backend() == "gloo"
+
+
+def _isend(dist, t, dst):
+    return dist.isend(t.cpu() if _stages(dist, t) else t, dst=dst)
+
+
+class _Recv:
+    """irecv into `t` (through a host buffer where the backend needs one); wait() completes the copy"""
+
+    def __init__(self, dist, t, src):
+        self.t = t
+        self.buf = torch.empty(t.shape, dtype=t.dtype) if _stages(dist, t) else t
+        self.req = dist.irecv(self.buf, src=src)
+
+    def wait(self):
+        self.req.wait()
+        if self.buf is not self.t:
+            self.t.copy_(self.buf)
+
+
+def _all_gather(dist, t):
+    world = dist.get_world_size()
+    if _stages(dist, t):
+        h = t.cpu()
+        outs = [torch.empty_like(h) for _ in range(world)]
+        dist.all_gather(outs, h)
+        return outs
+    outs = [torch.empty_like(t) for _ in range(world)]
+    dist.all_gather(outs, t)
+    return outs
+
+
 def gather_bitstreams(dist, sizes, packed, dst=0):
-    """final gather.  sizes: int32 [n_local] per-frame usize, packed: uint8 [sum(sizes)].
-    Returns on `dst` a list over ranks of (sizes, packed) in rank (= frame) order, elsewhere None."""
+    """final gather.  sizes: int32 [n_local] per-frame usize, packed: uint8 [sum(sizes)] -- device tensors on the GPU path (they
+    stay on the device end to end with RCCL).  Returns on `dst` a list over ranks of (sizes, packed) in rank (= frame) order,
+    on the caller's device; elsewhere None."""
     world, rank = dist.get_world_size(), dist.get_rank()
     meta = torch.tensor([sizes.numel(), packed.numel()], dtype=torch.int64, device=sizes.device)
-    metas = [torch.empty_like(meta) for _ in range(world)]
-    dist.all_gather(metas, meta)
+    metas = _all_gather(dist, meta)
     if rank == dst:
         res = []
         reqs = []
@@ -60,18 +96,18 @@ def gather_bitstreams(dist, sizes, packed, dst=0):
             s = torch.empty(n, dtype=sizes.dtype, device=sizes.device)
             p = torch.empty(nb, dtype=torch.uint8, device=packed.device)
             if n:
-                reqs.append(dist.irecv(s, src=r))
+                reqs.append(_Recv(dist, s, r))
             if nb:
-                reqs.append(dist.irecv(p, src=r))
+                reqs.append(_Recv(dist, p, r))
             res.append((s, p))
         for q in reqs:
             q.wait()
         return res
     reqs = []                                                  # both messages in flight at once; the root has posted every receive
     if sizes.numel():
-        reqs.append(dist.isend(sizes, dst=dst))
+        reqs.append(_isend(dist, sizes, dst))
     if packed.numel():
-        reqs.append(dist.isend(packed, dst=dst))
+        reqs.append(_isend(dist, packed, dst))
     for q in reqs:
         q.wait()
     return None
@@ -132,15 +168,25 @@ def range_depends_on_prior_state(bits, bpos, offsets, nentered, nblk, mode512=Tr
         return True
     if not first_is_iframe:
         return True                                           # the range continues a GOP of the caller's
+    import numpy as np
     bp = bpos.cpu().numpy().astype("int64")
     off = offsets.cpu().numpy().astype("int64")
-    first = bits[0].cpu().numpy()
-    for k in range(nblk):                                     # (b), and (c) for the resync of every block of the first frame
-        flag, _ = _block_end(first, int(off[0, k]), int(bp[0]), mode512)
+    rows = bits.cpu().numpy()                                  # one transfer for the whole range
+    first = rows[0]
+    # (b), and (c) for the resync of every block of the first frame.  Vectorised for the common case -- the entry byte IS a
+    # flag: COPY decides at once, FILL / NORMAL need no look here; only entries that have to slide take the scalar walk
+    o0 = off[0, :nblk]
+    inside = o0 < len(first)
+    eb = np.where(inside, first[np.minimum(o0, len(first) - 1)], 0)
+    if bool(((eb == COPY_FLAG) & inside).any()):
+        return True
+    slide = ~inside | ~np.isin(eb, (FILL_FLAG, NORMAL_FLAG, COPY_FLAG))
+    for k in np.nonzero(slide)[0]:
+        flag, _ = _block_end(first, int(o0[k]), int(bp[0]), mode512)
         if flag is None or flag == COPY_FLAG:
             return True
     for f in range(n):                                        # (c): the last block of every frame
-        flag, end = _block_end(bits[f].cpu().numpy(), int(off[f, nblk - 1]), int(bp[f]), mode512)
+        flag, end = _block_end(rows[f], int(off[f, nblk - 1]), int(bp[f]), mode512)
         if flag is None or (flag != COPY_FLAG and end > int(bp[f])):
             return True
     return False
@@ -158,9 +204,7 @@ def decode_sharded(dist, decode_range, n_frames, first_frame_count=0, prev=None,
     pix, dep = decode_range(lo, hi, prev if rank == 0 else None, prev_iframe if rank == 0 else None)
     dev = pix.device
     flag = torch.tensor([1 if (dep and rank > 0) else 0], dtype=torch.int64, device=dev)
-    flags = [torch.empty_like(flag) for _ in range(world)]
-    dist.all_gather(flags, flag)
-    need = [bool(int(f.item())) for f in flags]
+    need = [bool(int(f.item())) for f in _all_gather(dist, flag)]
 
     def last_state(p, r_lo, r_hi, in_prev, in_iframe):
         """(img_data, iframe_data) after the last frame of a decoded non-empty range"""
@@ -184,13 +228,13 @@ def decode_sharded(dist, decode_range, n_frames, first_frame_count=0, prev=None,
             last, snap = last_state(pix, lo, hi, in_prev, in_iframe)
             if snap is None:
                 snap = torch.zeros_like(last)                  # fresh decoder: zeroed iframe (:532-560)
-            dist.send(last.contiguous(), dst=r)
-            dist.send(snap.contiguous(), dst=r)
+            _isend(dist, last.contiguous(), r).wait()
+            _isend(dist, snap.contiguous(), r).wait()
         elif rank == r:
             shape = pix.shape[1:]
             in_prev = torch.empty(shape, dtype=pix.dtype, device=dev)
             in_iframe = torch.empty(shape, dtype=pix.dtype, device=dev)
-            dist.recv(in_prev, src=src)
-            dist.recv(in_iframe, src=src)
+            _Recv(dist, in_prev, src).wait()
+            _Recv(dist, in_iframe, src).wait()
             pix, _ = decode_range(lo, hi, in_prev, in_iframe)
     return lo, hi, pix

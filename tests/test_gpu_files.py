@@ -40,7 +40,9 @@ CASES = ["agmv_opt3_low_lzss_160x128", "agmv_opt1_mid_lzss_160x128", "agmv_opt2_
          "c2_agmv_opt3_low_lzss_320x240",
          # BASELINE.json configs 4 / 5 in shape (tests/golden/make_golden_large.py): a 1080p source through the GBA scaler
          # (121x81 read as 120x80, heavy PDIFS) and a 1280x720 OPT_III clip through AGMV_EncodeAGMV
-         "c4_agmv_gba1_low_lzss_1920x1080", "c5_agmv_opt3_low_lzss_1280x720"]
+         "c4_agmv_gba1_low_lzss_1920x1080", "c5_agmv_opt3_low_lzss_1280x720",
+         # config 4 at 256 source frames of 1080p (tests/golden/make_golden_r3.py): 127 encoded GBA frames, 1.6 GB of BMPs
+         "c4_256_agmv_gba1_low_lzss_1920x1080"]
 
 
 @pytest.mark.parametrize("name", CASES)
@@ -70,6 +72,52 @@ def test_file_roundtrip_matches_reference(golden, tmp_path, name):
         assert h.hexdigest() == g["decoded_bmps_sha"], "decoded BMPs differ from the reference's"
     if g["opt"] in (5, 6, 7):
         assert os.path.exists(tmp_path / "GBA_GEN_AGMV.h")
+
+
+def test_two_devices_write_the_same_file(golden, tmp_path):
+    """AGMV_DEVICES=2 (agmv_pipeline.c: batches round-robin over the devices' worker pairs, chunks written in frame order, a
+    palette table per device): config 2 in batches of 8 frames must give the one-device file.  On a one-GPU box both
+    "devices" are card 0 (AGMV_DEVICES_OVERSUBSCRIBE=1); on a node with two cards they are two cards."""
+    g = golden["files"]["c2_agmv_opt3_low_lzss_320x240"]
+    H.lib()
+    T, W, Hh = g["T"], g["W"], g["H"]
+    (tmp_path / "fr").mkdir()
+    for t in range(1, T + 1):
+        H.write_bmp(str(tmp_path / "fr" / ("f%d.bmp" % t)), S.synth_frame(W, Hh, t))
+    env = dict(os.environ, AGMV_DEVICES="2", AGMV_DEVICES_OVERSUBSCRIBE="1", AGMV_TRACE="1")
+    r = subprocess.run([sys.executable, "-c", DRIVER % H.SO, g["driver"], str(T), str(W), str(Hh), str(g["opt"]),
+                        str(g["quality"]), str(g["compression"]), "8"], cwd=str(tmp_path), env=env,
+                       stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=600)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    assert b"4 GPU workers" in r.stderr, r.stderr.decode()[-2000:]      # two worker pairs were really opened
+    data = open(tmp_path / "out.agmv", "rb").read()
+    assert hashlib.sha256(data).hexdigest() == g["file_sha"], "the two-device .agmv file differs from the reference's"
+
+
+def test_foxlogo_212_through_encodevideo(golden_dir, tmp_path):
+    """SURVEY.md section 4's real-content known answers: the reference's AGMV_EncodeVideo over its own 212 foxlogo frames
+    (OPT_III, LOW quality, LZSS) writes a 156-frame file with sha ad91dc37..., which decodes to BMPs with sha ae2330f7....
+    The frames travel as pixels (tests/golden/foxlogo212.npz); the hashes are the compiled reference's."""
+    import json
+    import numpy as np
+    g = json.load(open(os.path.join(golden_dir, "golden_r3.json")))["encodevideo_212"]
+    assert g["file_sha"].startswith("ad91dc37") and g["decoded_bmps_sha"].startswith("ae2330f7")
+    H.lib()
+    rgb = np.load(os.path.join(golden_dir, "foxlogo212.npz"))["rgb"].astype(np.uint32)
+    frames = rgb[..., 0] << 16 | rgb[..., 1] << 8 | rgb[..., 2]
+    (tmp_path / "fr").mkdir()
+    for k in range(212):
+        H.write_bmp(str(tmp_path / "fr" / ("f%d.bmp" % (k + 1))), frames[k])
+    r = subprocess.run([sys.executable, "-c", DRIVER % H.SO, "video", "212", "320", "240", "3", "3", "1", "64"], cwd=str(tmp_path),
+                       stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=600)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    data = open(tmp_path / "out.agmv", "rb").read()
+    assert len(data) == g["file_len"] and int.from_bytes(data[4:8], "little") == g["frames"] == 156
+    assert hashlib.sha256(data).hexdigest() == g["file_sha"], "the .agmv file differs from the reference's"
+    h = hashlib.sha256()
+    for k in range(1, g["frames"] + 1):
+        h.update(open(tmp_path / ("quick_export_%d.bmp" % k), "rb").read())
+    assert h.hexdigest() == g["decoded_bmps_sha"], "decoded BMPs differ from the reference's"
 
 
 def test_foxlogo_through_the_readme_flow(golden_fox, foxlogo, tmp_path):

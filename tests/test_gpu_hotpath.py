@@ -68,19 +68,31 @@ def test_lut_golden_and_random(torch, hip, golden_dir):
         assert (e == g[key]).all()
 
 
-def test_lut_exhaustive_all_colours(torch, hip):
-    """all 2^24 colours of one palette pair against the oracle (E2/E3 tie rules included)."""
-    p0, p1 = S.random_palettes(123)
-    p1[:8] = p0[:8]
-    hip.set_palette(p0, p1, True)
+@pytest.mark.parametrize("which", ["random123_tie8", "foxlogo"])
+def test_lut_exhaustive_all_colours(torch, hip, golden_dir, foxlogo, which):
+    """The COMPLETE 2^24-entry colour -> entry table -- the one object every encoded byte depends on -- against the compiled
+    reference's AGMV_FindNearestEntry / AGMV_FindNearestColor over all colours (sha256 of the table in colour order, made by
+    tests/golden/make_golden_r3.py), both colour modes: a palette pair with the cross-palette tie block p1[:8] = p0[:8], and
+    the palette the reference builds for its own foxlogo clip.  Plus a sample against the oracle restatement."""
+    import hashlib
+    import json
+    g = json.load(open(os.path.join(golden_dir, "golden_r3.json")))["lut_sha"][which]
+    if which == "foxlogo":
+        p0, p1 = foxlogo["p0"], foxlogo["p1"]
+    else:
+        p0, p1 = S.random_palettes(123)
+        p1[:8] = p0[:8]
     allc = np.arange(1 << 24, dtype=np.uint32)
-    e = to_u16(hip.quantise_dev(dev_u32(torch, allc)))
-    # oracle on a strided 1/16 sample + one dense 64K run (the full 2^24 x 512 search is ~20 s of CPU)
-    sample = np.ascontiguousarray(np.concatenate([allc[5::16], allc[0x7F0000:0x800000]]))
-    ref = np.zeros(len(sample), np.uint16)
-    O.oracle().orc_quantise(p0, p1, 1, sample, len(sample), ref)
-    got = np.concatenate([e[5::16], e[0x7F0000:0x800000]])
-    assert (got == ref).all()
+    dall = dev_u32(torch, allc)
+    for mode512, key in ((True, "m512"), (False, "m256")):
+        hip.set_palette(p0, p1, mode512)
+        e = to_u16(hip.quantise_dev(dall))
+        assert hashlib.sha256(e.astype("<u2").tobytes()).hexdigest() == g[key], "%s %s: the table differs from the reference's" % (which, key)
+        if mode512:
+            sample = np.ascontiguousarray(np.concatenate([allc[5::16], allc[0x7F0000:0x800000]]))
+            ref = np.zeros(len(sample), np.uint16)
+            O.oracle().orc_quantise(p0, p1, 1, sample, len(sample), ref)
+            assert (np.concatenate([e[5::16], e[0x7F0000:0x800000]]) == ref).all()
 
 
 # ------------------------------------------------------------------------------- K1: encode
@@ -719,7 +731,12 @@ def test_c3_full_batch_vs_oracle(torch, hip):
     if free < 30 * (1 << 30):
         pytest.skip("needs ~25 GB of device memory")
     frames = hip.synth_dev(W, H, 0, T)
-    p0, p1 = S.content_palettes([S.synth_frame(W, H, t) for t in range(2)])
+    # the palette bench.py encodes with: AGMV_HIGH_QUALITY histogram over the whole clip (GPU pass 1) + the reference's pick
+    hist = hip.histogram_dev(frames.reshape(-1), 1).cpu().numpy().view(np.uint32)
+    import hostlib as HL
+    q0, q1 = np.zeros(256, np.uint64), np.zeros(256, np.uint64)
+    HL.lib().AGMV_BuildPalette(hist, 1, 3, q0, q1)
+    p0, p1 = q0.astype(np.uint32), q1.astype(np.uint32)
     hip.set_palette(p0, p1, True)
     out, sizes = hip.encode_dev(frames, T, W, H)
     hip.check()

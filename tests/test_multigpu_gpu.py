@@ -1,5 +1,6 @@
 """N > 1 with the REAL hot path: ranks shard one clip by GOP range, every rank encodes / decodes its range on the GPU
-through the C-ABI, the final gather (libagmv_amd.shard, gloo here; RCCL in bench.py) puts the bitstreams together on
+through the C-ABI, the final gather (libagmv_amd.shard: DEVICE tensors, as with RCCL in bench.py; the gloo backend used
+here stages them through the host inside shard.py, so the backend string is all that differs) puts the bitstreams together on
 rank 0 -- which must hold exactly what ONE process makes of the whole clip, and what the oracle says.  Sharded decode uses
 the decoder's own account of whether a range depends on the state before it (agmv_hip_decode_prior_dependent).
 On a one-GPU box both ranks use device 0 (two processes on the card); on a multi-GPU node rank r takes device r."""
@@ -36,13 +37,14 @@ def _worker(rank, world, port, q, kind):
     d = torch.from_numpy(frames[lo:hi].view(np.int32)).cuda()
     out, sizes = hip.encode_dev(d, hi - lo, W, H, first_frame_count=lo)
     hip.check()
-    got = shard.gather_bitstreams(dist, sizes.cpu(), shard.pack_frames(out, sizes).cpu(), dst=0)
+    got = shard.gather_bitstreams(dist, sizes, shard.pack_frames(out, sizes), dst=0)      # DEVICE tensors, as bench.py passes them to RCCL
+    assert rank != 0 or all(s_.is_cuda and p_.is_cuda for s_, p_ in got)
     ok = True
     bits = None
     if rank == 0:
         bits = []
         for s_, p_ in got:
-            bits += [x.numpy() for x in shard.split_packed(s_, p_)]
+            bits += [x.cpu().numpy() for x in shard.split_packed(s_, p_)]
         enc = O.OracleEncoder(W, H, True, p0, p1)
         ok = len(bits) == T and all(len(bits[t]) == len(e) and (bits[t] == e).all() for t, e in ((t, enc.encode(frames[t])) for t in range(T)))
     # every rank needs the whole stream for the decode half: broadcast it from the root
@@ -70,13 +72,12 @@ def _worker(rank, world, port, q, kind):
         dbits = torch.from_numpy(slab).cuda()
         dbpos = torch.tensor([len(x) for x in bits[a:b]], dtype=torch.int32).cuda()
         offs, nent = hip.parse_dev(dbits, dbpos, b - a, W, H)
-        pix = hip.decode_dev(dbits, dbpos, offs, nent, b - a, W, H, a, prev=prev.cuda() if prev is not None else None,
-                             prev_iframe=prev_iframe.cuda() if prev_iframe is not None else None)
+        pix = hip.decode_dev(dbits, dbpos, offs, nent, b - a, W, H, a, prev=prev, prev_iframe=prev_iframe)   # hand-off state arrives as device tensors
         torch.cuda.synchronize()
-        return pix.cpu(), hip.decode_depends_on_prior(W, H)
+        return pix, hip.decode_depends_on_prior(W, H)
 
     a, b, pix = shard.decode_sharded(dist, decode_range, T)
-    ok = ok and all(bool((pix[f - a].numpy().view(np.uint32).ravel() == ref[f]).all()) for f in range(a, b))
+    ok = ok and pix.is_cuda and all(bool((pix[f - a].cpu().numpy().view(np.uint32).ravel() == ref[f]).all()) for f in range(a, b))
     if kind == "clean":
         ok = ok and len(calls) == 1                            # nothing the encoder emits needs a hand-off
     elif rank > 0:
