@@ -408,7 +408,8 @@ def secondary_legs(torch, local_rank, dev):
         torch.cuda.synchronize()
         p0 = np.zeros(256, np.uint64)
         p1 = np.zeros(256, np.uint64)
-        host_lib().AGMV_BuildPalette(hist.cpu().numpy().view(np.uint32).ctypes.data, 3, 3, p0.ctypes.data, p1.ctypes.data)
+        hist_np = hist.cpu().numpy().view(np.uint32)            # (kept alive across the call: ctypes takes a bare pointer)
+        host_lib().AGMV_BuildPalette(hist_np.ctypes.data, 3, 3, p0.ctypes.data, p1.ctypes.data)
         h2.set_palette(p0.astype(np.uint32), p1.astype(np.uint32), True)
         h2.enable_timing(True)
         big = h2.synth_dev(W, H, 0, 8192, device=dev)

@@ -477,6 +477,7 @@ struct EncGeo {
 // ENTRIES: the input planes hold ENTRIES (one per 32-bit word, pal_num << 8 | index) instead of pixels -- the table look-ups
 // are skipped and classification + emission run on the caller's entries (AGMV_AssembleIFrameBitstream /
 // AGMV_AssemblePFrameBitstream on a given AGMV_ENTRY plane, src/agmv_encode.c:354-527).
+typedef uint32_t px4 __attribute__((ext_vector_type(4)));   // a native vector (HIP's uint4 is a struct: asm cannot tie it to a register tuple)
 template <bool M512, bool ENTRIES>
 __global__ __launch_bounds__(ENC_T, ENC_WPE) void k_encode(EncArgs A)
 {
@@ -530,22 +531,22 @@ __global__ __launch_bounds__(ENC_T, ENC_WPE) void k_encode(EncArgs A)
 		g.p0b = ((qy0 * 4 + prow) * A.w + g.qx0 * 4) * 4u;
 		g.path = (g.wbase + WBLK > A.nblk || g.wbx + WBLK > 2 * A.bw) ? 2 : (g.wbx + WBLK > A.bw ? 1 : 0);
 	};
-	auto load_frame = [&](const EncGeo& g, const uint32_t* fp, uint4 (&dst)[4]) {
+	auto load_frame = [&](const EncGeo& g, const uint32_t* fp, px4 (&dst)[4]) {
 		const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)fp, 0, (int)(npx * 4u), 0x00020000);
 		const uint32_t w3b = 12u * A.w;
 		if (g.path == 0) {
 #pragma unroll
-			for (int i = 0; i < 4; i++) dst[i] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rs, g.p0b + 256 * i, 0, ENC_PIXAUX));
+			for (int i = 0; i < 4; i++) dst[i] = __builtin_bit_cast(px4, __builtin_amdgcn_raw_buffer_load_b128(rs, g.p0b + 256 * i, 0, ENC_PIXAUX));
 		} else if (g.path == 1) {
 #pragma unroll
 			for (int i = 0; i < 4; i++)
-				dst[i] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rs, g.p0b + 256 * i + (g.qx0 + 16 * i >= A.bw ? w3b : 0u), 0, ENC_PIXAUX));
+				dst[i] = __builtin_bit_cast(px4, __builtin_amdgcn_raw_buffer_load_b128(rs, g.p0b + 256 * i + (g.qx0 + 16 * i >= A.bw ? w3b : 0u), 0, ENC_PIXAUX));
 		} else {
 #pragma unroll
 			for (int i = 0; i < 4; i++) {
 				uint32_t qx, qy;
 				locate(g, g.wbase + jb + 16 * i, qx, qy);
-				dst[i] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rs, ((qy * 4 + prow) * A.w + qx * 4) * 4u, 0, ENC_PIXAUX));
+				dst[i] = __builtin_bit_cast(px4, __builtin_amdgcn_raw_buffer_load_b128(rs, ((qy * 4 + prow) * A.w + qx * 4) * 4u, 0, ENC_PIXAUX));
 			}
 		}
 	};
@@ -603,13 +604,14 @@ __global__ __launch_bounds__(ENC_T, ENC_WPE) void k_encode(EncArgs A)
 	uint32_t it = 0;                                           // item number (tags / slots)
 	bool new_tile = true;
 	uint32_t ip[8];                                            // the GOP's I-frame entries of this block, two u16 per register
-	uint4 pxs[ENC_PFDEPTH][4];
+	px4 pxs[ENC_PFDEPTH][4];
 #pragma unroll
 	for (int d = 0; d < ENC_PFDEPTH; d++)
 		if (pf.have) { load_frame(pf.g, A.pix + (size_t)pf.f * npx, pxs[d]); advance(pf, true); }
 	bool have_prev = false;                                    // item it-1: tile, frame, bytes of this wave
 	uint32_t p_tile = 0, p_len = 0;
 	int p_f = 0;
+	unsigned long long pre_next = ST_PREFIX;                   // the status window the NEXT item's duty wave will look back through
 
 #ifdef ENC_PROF
 	uint32_t prof[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -619,16 +621,17 @@ __global__ __launch_bounds__(ENC_T, ENC_WPE) void k_encode(EncArgs A)
 #define PSTAMP(k) do { } while (0)
 #endif
 	uint32_t prof_sink = 0; (void)prof_sink;
-	auto body = [&](uint4 (&px)[4]) -> bool {                 // one item: consumes px and refills it with the item ENC_PFDEPTH ahead
+	auto body = [&](px4 (&px)[4]) -> bool {                 // one item: consumes px and refills it with the item ENC_PFDEPTH ahead
 		EncGeo& g = cur.g;
 		const int f = cur.f;
 		const uint32_t slot = it & (DF_SLOTS - 1), tag = (it + 1) & 0xffffu;
 		const uint32_t pslot = (it - 1) & (DF_SLOTS - 1), ptag = it & 0xffffu;
-		// (L) the look-back of item it-1 is the duty of ONE wave (rotating), done while its own table look-ups are in
-		// flight: the status window is loaded first, so it has landed when the look-ups have (in-order counter)
+		// (L) the look-back of item it-1 is the duty of ONE wave (rotating).  Its status window was requested at the END of
+		// item it-1, behind that item's pixel prefetch (pre_next): the status words bypass the caches -- a fabric round trip,
+		// several times the latency of a table look-up -- and the memory counter retires in order, so requested here, ahead
+		// of the look-ups, the window would hold back every entry of the duty wave, and with it gbase[] for all eight waves
 		const bool duty = have_prev && wave == (int)(it % ENC_WAVES);
-		unsigned long long pre = ST_PREFIX;
-		if (duty && p_tile != 0) pre = st_load(A.status + (size_t)p_f * A.tpf, (int)p_tile - 1 - lane);
+		const unsigned long long pre = pre_next;
 		auto resolve_prev = [&]() {                            // tile offset of item it-1, usize of the frame, gbase[]
 			unsigned long long* st = A.status + (size_t)p_f * A.tpf;
 			uint32_t excl = 0;
@@ -707,21 +710,19 @@ __global__ __launch_bounds__(ENC_T, ENC_WPE) void k_encode(EncArgs A)
 #if ENC_PRIO
 		__builtin_amdgcn_s_setprio(ENC_PRIO);
 #endif
+		uint32_t ep[8], e0, len;
+		bool copy, fill;
+		{
 		// ---- (Q) colour -> entry through the exact table, lane = (block, row)
 		uint32_t eq[16];
 		const uint32_t pxv[16] = {px[0].x, px[0].y, px[0].z, px[0].w, px[1].x, px[1].y, px[1].z, px[1].w,
 		                          px[2].x, px[2].y, px[2].z, px[2].w, px[3].x, px[3].y, px[3].z, px[3].w};
-#define LUT_OFF(c) lut_offset(c)
 #pragma unroll
 		for (int k = 0; k < 16; k++) {
 			if (ENTRIES) eq[k] = pxv[k] & (M512 ? 0x1FFu : 0xFFu);
-			else {
-				eq[k] = (uint16_t)__builtin_amdgcn_raw_buffer_load_b16(lut_rs, LUT_OFF(pxv[k]), 0, ENC_LUTAUX);
-			}
+			else eq[k] = (uint16_t)__builtin_amdgcn_raw_buffer_load_b16(lut_rs, lut_offset(pxv[k]), 0, ENC_LUTAUX);
 		}
 		PSTAMP(0);
-		// issued right BEHIND the look-ups (the memory counter retires in order: ahead of them they would have to land
-		// before the first entry is usable), and before the wait for the entries
 #if ENC_PRIO
 		__builtin_amdgcn_s_setprio(0);
 #endif
@@ -740,7 +741,6 @@ __global__ __launch_bounds__(ENC_T, ENC_WPE) void k_encode(EncArgs A)
 		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 		__builtin_amdgcn_wave_barrier();
 		// ---- transpose: lane = block reads its 16 entries (32 contiguous bytes), kept PACKED two per register
-		uint32_t ep[8];
 		{
 			const uint4 lo = *(const uint4*)(scratch + lane * 32), hi = *(const uint4*)(scratch + lane * 32 + 16);
 			ep[0] = lo.x; ep[1] = lo.y; ep[2] = lo.z; ep[3] = lo.w; ep[4] = hi.x; ep[5] = hi.y; ep[6] = hi.z; ep[7] = hi.w;
@@ -748,20 +748,21 @@ __global__ __launch_bounds__(ENC_T, ENC_WPE) void k_encode(EncArgs A)
 		// ---- (C) block tests. count1 = CompareIFrameBlock vs the top-left entry colour
 		// (src/agmv_encode.c:302-352), count2 = ComparePFrameBlock vs the I-frame entries
 		// (src/agmv_encode.c:240-300); one matrix bit per pixel (the shifter uses the low 5 bits of its amount).
-		const uint32_t e0 = ep[0] & 0xffffu, row0 = e0 * MROW;
+		e0 = ep[0] & 0xffffu;
+		const uint32_t row0 = e0 * MROW;
 		uint32_t acc1 = 0, acc2 = 0, nesc = 0;
 		// (the I / P choice is wave-uniform: unswitched by hand -- with the test inside the unrolled loop the compiler
 		//  branches per entry pair and waits for each pair's two matrix words before it issues the next reads)
 		if (is_i) block_tests<M512, false>(ep, ip, s_mtx, row0, acc1, acc2, nesc);
 		else block_tests<M512, true>(ep, ip, s_mtx, row0, acc1, acc2, nesc);
 		const uint32_t count1 = __popc(acc1), count2 = __popc(acc2);
-		const bool copy = !is_i && count2 >= COPY_COUNT;       // COPY has priority, :465
-		const bool fill = !copy && count1 >= FILL_COUNT;
-		uint32_t len;
+		copy = !is_i && count2 >= COPY_COUNT;                  // COPY has priority, :465
+		fill = !copy && count1 >= FILL_COUNT;
 		if (copy) len = 1;
 		else if (fill) len = M512 ? (2u + ((e0 & 0xffu) >= 127u ? 1u : 0u)) : 2u;
 		else len = 17u + nesc;
 		if (!g.valid) len = 0;
+		}
 
 		if (is_i) {                                            // iframe_entries = img_entry, :626-630
 #pragma unroll
@@ -837,12 +838,14 @@ __global__ __launch_bounds__(ENC_T, ENC_WPE) void k_encode(EncArgs A)
 		}
 		PSTAMP(5);
 		if (have_prev) copy_out_prev();
-		prefetch_next();
+		prefetch_next();                                       // LAST in the item: any later wait of the item (the compiler places conservative ones at branch joins) would drain these loads -- requested right behind the entries they measured 0.98 against 0.72 ms per 256 frames
 		PSTAMP(7);
 
 		// ---- next item
 		have_prev = true; p_tile = g.tile; p_f = f; p_len = wtot;
 		it++;
+		pre_next = ST_PREFIX;
+		if (wave == (int)(it % ENC_WAVES) && p_tile != 0) pre_next = st_load(A.status + (size_t)p_f * A.tpf, (int)p_tile - 1 - lane);
 		new_tile = advance(cur, false);
 		return true;
 	};

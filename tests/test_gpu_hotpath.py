@@ -144,6 +144,40 @@ def test_encode_vs_oracle_shapes_and_content(torch, hip, mode512, shape):
         assert len(outs[t]) == len(exp) and (outs[t] == exp).all(), "frame %d first diff %s" % (t, first_diff(outs[t], exp))
 
 
+@pytest.mark.parametrize("mode512", [True, False])
+def test_encode_static_pictures(torch, hip, mode512):
+    """Static pictures (every P-frame block is a COPY, src/agmv_encode.c:462-467): whole frames repeated inside a GOP and
+    across a GOP boundary, a picture that is static in its left part only (waves of 64 blocks entirely inside it, entirely
+    outside, straddling), pixels that differ only above bit 23, a batch that starts inside a GOP, against the oracle."""
+    W, H = 1024, 32                                            # 256 blocks per block row: four waves per row
+    rng = np.random.default_rng(77)
+    base = rng.integers(0, 1 << 24, size=(H, W), dtype=np.uint32)
+    base[:, 640:] = 0x203040                                   # flat right part
+    frames = [base.copy() for _ in range(12)]
+    frames[2] = base ^ np.uint32(0x01000000)                   # same colours, different top byte
+    for t in (5, 6, 7, 9):                                     # GOP 4..7 / 8..11: left 5/8 static, the rest moves
+        frames[t] = base.copy()
+        frames[t][:, 640:] = 0x203040 + 0x010101 * t
+    frames[10][:, 100:164] ^= np.uint32(0x3)                   # one wave's worth of change inside the static part
+    frames = np.stack(frames)
+    p0, p1 = S.content_palettes(frames[:4])
+    hip.set_palette(p0, p1, mode512)
+    enc = O.OracleEncoder(W, H, mode512, p0, p1)
+    exp = [enc.encode(f) for f in frames]
+    outs = gpu_encode(torch, hip, frames)
+    for t in range(len(frames)):
+        assert len(outs[t]) == len(exp[t]) and (outs[t] == exp[t]).all(), "frame %d first diff %s" % (t, first_diff(outs[t], exp[t]))
+    # the same clip in two batches, the second one starting inside GOP 4..7 with the I-frame's entries handed over
+    d = torch.from_numpy(frames.view(np.int32)).cuda()
+    ient = torch.zeros(W * H, dtype=torch.int16, device="cuda")
+    o1, s1 = hip.encode_dev(d[:6], 6, W, H, 0, ientries=ient)
+    o2, s2 = hip.encode_dev(d[6:], 6, W, H, 6, ientries=ient)
+    hip.check()
+    got = [o1[t, :int(s1[t])].cpu().numpy() for t in range(6)] + [o2[t, :int(s2[t])].cpu().numpy() for t in range(6)]
+    for t in range(12):
+        assert len(got[t]) == len(exp[t]) and (got[t] == exp[t]).all(), "two batches, frame %d" % t
+
+
 def test_encode_batches_continue_a_gop(torch, hip):
     """frame_count continuity: encoding 11 frames as batches of 1,2,5,3 (starting inside GOPs, with
     the I-frame entry plane carried between calls like agmv->iframe_entries) equals one batch."""
