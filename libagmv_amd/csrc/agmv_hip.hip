@@ -978,6 +978,7 @@ struct ParseArgs {
 	uint32_t* nentered;
 	uint32_t n_frames, nblk;
 	const uint32_t* fstate; // != NULL: only the frames the fast path gave up on (fstate[f] == FS_BAD) are parsed here
+	const uint32_t* nbad;   // != NULL: how many frames are FS_BAD (0: every kernel of this path returns at once, without a look at the frames)
 	unsigned long long* vm; // != NULL: the result goes out as entry BITS (the fast parser's bitmaps, [frame][maxR * FOWN] words of 64 bytes of stream) instead of offsets[]
 	uint32_t maxR;
 };
@@ -986,6 +987,7 @@ constexpr uint32_t FS_OK = 0, FS_TODO = 1, FS_BAD = 2;
 __global__ __launch_bounds__(64) void k_parse_prefix(ParseArgs A)
 {
 	const int lane = threadIdx.x;
+	if (A.nbad && *A.nbad == 0) return;
 	uint32_t run = 0;
 	for (uint32_t f0 = 0; f0 < A.n_frames; f0 += 64) {
 		const uint32_t f = f0 + lane;
@@ -1103,6 +1105,7 @@ __global__ __launch_bounds__(64) void k_parse_chunks(ParseArgs A)
 	__shared__ ParseLds<2> S;
 	__shared__ uint16_t nn[2][PC];                             // node -> blocks counted along its jump (ping-pong)
 	const int lane = threadIdx.x;
+	if (A.nbad && *A.nbad == 0) return;
 	// 2-D grid: y strides over frames, x over the chunks of a frame (no search for the frame of a chunk)
 	for (uint32_t f = blockIdx.y; f < A.n_frames; f += gridDim.y) {
 	const uint32_t g0 = A.cum[f], nch = A.cum[f + 1] - g0, bpos = A.bpos[f];
@@ -1158,10 +1161,11 @@ __global__ __launch_bounds__(64) void k_parse_chunks(ParseArgs A)
 constexpr int PSB = 32;
 __global__ __launch_bounds__(64) void k_parse_stitch(ParseArgs A)
 {
-	const uint32_t f = blockIdx.x;
 	const int lane = threadIdx.x;
+	if (A.nbad && *A.nbad == 0) return;
+	for (uint32_t f = blockIdx.x; f < A.n_frames; f += gridDim.x) {
 	const uint32_t c0 = A.cum[f], nch = A.cum[f + 1] - c0;     // nch >= 1 for a frame that is parsed here
-	if (nch == 0) return;
+	if (nch == 0) continue;
 	const uint16_t* rows = A.summ + (size_t)c0 * 33 + (lane < 33 ? lane : 0);
 	uint32_t o = 0, kb = 0;
 	uint32_t nxt[PSB];
@@ -1186,6 +1190,7 @@ __global__ __launch_bounds__(64) void k_parse_stitch(ParseArgs A)
 		if (lane < PSB && c + lane < nch) A.centry[c0 + c + lane] = mine;
 	}
 	if (lane == 0) A.nentered[f] = min(A.nblk, kb + 1u);
+	}
 }
 
 template <bool M512>
@@ -1196,6 +1201,7 @@ __global__ __launch_bounds__(64) void k_parse_emit(ParseArgs A)
 	uint8_t* mark = S.b;                                       // chain marks: in the staged bytes' space once the nodes are built
 	static_assert(PEL >= 2 && PC + PHALO >= PC, "rank_at / npos borrow jl[PEL-1] / jl[PEL], the marks borrow the bytes");
 	const int lane = threadIdx.x;
+	if (A.nbad && *A.nbad == 0) return;
 	for (uint32_t f = blockIdx.y; f < A.n_frames; f += gridDim.y) {
 	const uint32_t g0 = A.cum[f], nch = A.cum[f + 1] - g0, bpos = A.bpos[f];
 	const uint8_t* fbits = A.bits + (size_t)f * A.stride;
@@ -1308,6 +1314,7 @@ struct FpArgs {
 	uint32_t* offsets;
 	uint32_t* nentered;
 	uint32_t n_frames, nblk, maxR;
+	uint32_t* nbad;             // frames given up (FS_BAD), counted by k_fp_finish
 	uint32_t* tidx;             // [n_frames][tpfd + 1] byte position at which the first block of every k_decode tile is entered (TIDX_NONE: not entered)
 	uint32_t tpfd;              // k_decode tiles per frame
 };
@@ -1487,11 +1494,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
 {
 	__shared__ uint32_t s_b[FP_LDS];
 	const int lane = threadIdx.x;
-	const uint32_t f = blockIdx.y;
-	const uint32_t bpos = A.bpos[f];
-	const uint32_t nreg = min(bpos / FRB + 1u, A.maxR);        // positions 0 .. bpos can hold nodes
-	for (uint32_t r = blockIdx.x; r < nreg; r += gridDim.x)
-		fp_walk_region<M512>(A, s_b, f, r, r == 0 ? 0u : FX_UNSET, bpos, lane);   // block 0 is entered at byte 0
+	for (uint32_t f = blockIdx.y; f < A.n_frames; f += gridDim.y) {   // (many small frames: the grid is capped, rows stride over the frames)
+		const uint32_t bpos = A.bpos[f];
+		const uint32_t nreg = min(bpos / FRB + 1u, A.maxR);    // positions 0 .. bpos can hold nodes
+		for (uint32_t r = blockIdx.x; r < nreg; r += gridDim.x)
+			fp_walk_region<M512>(A, s_b, f, r, r == 0 ? 0u : FX_UNSET, bpos, lane);   // block 0 is entered at byte 0
+	}
 }
 
 // one wave per frame: prove the regions (see above), walk again those that are not, number the blocks
@@ -1519,7 +1527,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
 		}
 		if (bad == 0xFFFFFFFFu) break;
 		if (budget-- == 0) {
-			if (lane == 0) A.fstate[f] = FS_BAD;
+			if (lane == 0) { A.fstate[f] = FS_BAD; atomicAdd(A.nbad, 1u); }
 			return;
 		}
 		const uint32_t want = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&rec[bad - 1].y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
@@ -1618,8 +1626,8 @@ __device__ __forceinline__ uint32_t select64(unsigned long long v, uint32_t k)
 __global__ __launch_bounds__(64) void k_fp_tiles(FpArgs A)
 {
 	const int lane = threadIdx.x;
-	const uint32_t f = blockIdx.y;
-	if (A.fstate[f] == FS_BAD) return;                         // (cannot happen behind k_fp_recount; a frame without bitmaps has no tiles)
+	for (uint32_t f = blockIdx.y; f < A.n_frames; f += gridDim.y) {
+	if (A.fstate[f] == FS_BAD) continue;                       // (cannot happen behind k_fp_recount; a frame without bitmaps has no tiles)
 	const uint32_t nreg = min(A.bpos[f] / FRB + 1u, A.maxR);
 	uint32_t* tx = A.tidx + (size_t)f * (A.tpfd + 1);
 	for (uint32_t r = blockIdx.x; r < nreg; r += gridDim.x) {
@@ -1637,6 +1645,7 @@ __global__ __launch_bounds__(64) void k_fp_tiles(FpArgs A)
 			if (target >= first && target < first + n) tx[m] = r * FRB + (uint32_t)lane * FC + select64(V, target - first);
 		}
 	}
+	}
 }
 
 // Frames the fast parser gave up on, after the robust kernels have set their entry bits (k_parse_emit, bitmap form): count
@@ -1645,6 +1654,7 @@ constexpr uint32_t FS_FIXED = 3;
 __global__ __launch_bounds__(64) void k_fp_recount(FpArgs A)
 {
 	const int lane = threadIdx.x;
+	if (*A.nbad == 0) return;
 	for (uint32_t f = blockIdx.x; f < A.n_frames; f += gridDim.x) {
 		if (A.fstate[f] != FS_BAD) continue;
 		const uint32_t nreg = min(A.bpos[f] / FRB + 1u, A.maxR);
@@ -2784,7 +2794,7 @@ static int check_slab(const uint8_t* d_bits, size_t stride)
 // ordered); fstate != NULL: only the frames marked FS_BAD
 static int parse_launch_robust(agmv_hip_ctx* c, const uint8_t* d_bits, size_t stride, const uint32_t* d_bpos, uint32_t n_frames,
                                uint32_t nblk, uint32_t* d_offsets, uint32_t* d_nentered, size_t ws_frames, const uint32_t* fstate, hipStream_t s,
-                               unsigned long long* vm = nullptr, uint32_t maxR = 0)
+                               unsigned long long* vm = nullptr, uint32_t maxR = 0, const uint32_t* nbad = nullptr)
 {
 	const size_t cpf = (stride + PC) / PC, maxchunks = cpf * ws_frames;
 	const size_t need = ws_frames + 1 + maxchunks + (maxchunks * 33 + 1) / 2 + 16;   // dwords: cum | centry | summ (u16)
@@ -2798,7 +2808,7 @@ static int parse_launch_robust(agmv_hip_ctx* c, const uint8_t* d_bits, size_t st
 	memset(&A, 0, sizeof(A));
 	A.bits = d_bits; A.stride = stride; A.bpos = d_bpos; A.offsets = d_offsets; A.nentered = d_nentered;
 	A.cum = c->d_parse_ws; A.centry = A.cum + ws_frames + 1; A.summ = (uint16_t*)(A.centry + maxchunks);
-	A.n_frames = n_frames; A.nblk = nblk; A.fstate = fstate; A.vm = vm; A.maxR = maxR;
+	A.n_frames = n_frames; A.nblk = nblk; A.fstate = fstate; A.vm = vm; A.maxR = maxR; A.nbad = nbad;
 	// the exception path (fstate): a few rows of workgroups stride over the frames and leave those that are not FS_BAD at
 	// once -- with one row per frame the three gated launches cost 0.03 ms per 1024 frames for zero frames to parse
 	const dim3 gy(1, fstate ? (n_frames < 64u ? n_frames : 64u) : (n_frames < 65535u ? n_frames : 65535u));
@@ -2817,7 +2827,7 @@ static int parse_launch_robust(agmv_hip_ctx* c, const uint8_t* d_bits, size_t st
 	if (c->mode512) hipLaunchKernelGGL(k_parse_chunks<true>, grid, dim3(64), 0, s, A);
 	else            hipLaunchKernelGGL(k_parse_chunks<false>, grid, dim3(64), 0, s, A);
 	CK(hipGetLastError());
-	hipLaunchKernelGGL(k_parse_stitch, dim3(n_frames), dim3(64), 0, s, A);
+	hipLaunchKernelGGL(k_parse_stitch, dim3(fstate ? (n_frames < 1024u ? n_frames : 1024u) : n_frames), dim3(64), 0, s, A);
 	CK(hipGetLastError());
 	if (c->mode512) hipLaunchKernelGGL(k_parse_emit<true>, grid, dim3(64), 0, s, A);
 	else            hipLaunchKernelGGL(k_parse_emit<false>, grid, dim3(64), 0, s, A);
@@ -2841,7 +2851,7 @@ static int parse_launch(agmv_hip_ctx* c, const uint8_t* d_bits, size_t stride, c
 	const uint32_t tpfd = (nblk + DEC_T - 1) / DEC_T;
 	const size_t b_rec = nreg * sizeof(uint4), b_vm = nreg * FOWN * 8, b_kb = nreg * 4, b_fs = ((ws_frames * 4 + 15) & ~(size_t)15);
 	const size_t b_tx = bitmap ? (((size_t)ws_frames * (tpfd + 1) * 4 + 15) & ~(size_t)15) : 0;
-	const size_t need = b_rec + b_vm + b_kb + b_fs + b_tx;
+	const size_t need = b_rec + b_vm + b_kb + b_fs + b_tx + 16;
 	if (need > c->fp_ws_cap) {
 		if (c->d_fp_ws) CK(hipFree(c->d_fp_ws));
 		c->d_fp_ws = nullptr; c->fp_ws_cap = 0;
@@ -2854,6 +2864,7 @@ static int parse_launch(agmv_hip_ctx* c, const uint8_t* d_bits, size_t stride, c
 	uint8_t* w = (uint8_t*)c->d_fp_ws;
 	A.rec = (uint4*)w; A.vm = (unsigned long long*)(w + b_rec); A.kb = (uint32_t*)(w + b_rec + b_vm); A.fstate = (uint32_t*)(w + b_rec + b_vm + b_kb);
 	A.tidx = bitmap ? (uint32_t*)(w + b_rec + b_vm + b_kb + b_fs) : nullptr; A.tpfd = tpfd;
+	A.nbad = (uint32_t*)(w + b_rec + b_vm + b_kb + b_fs + b_tx);
 	A.n_frames = n_frames; A.nblk = nblk; A.maxR = (uint32_t)maxR;
 	uint32_t gx = (uint32_t)(((size_t)c->n_cu * 512 + n_frames - 1) / n_frames);
 	if (gx < 32) gx = 32;
@@ -2861,10 +2872,20 @@ static int parse_launch(agmv_hip_ctx* c, const uint8_t* d_bits, size_t stride, c
 	if (getenv("AGMV_PARSE_GX")) gx = (uint32_t)atoi(getenv("AGMV_PARSE_GX"));   // tuning aid
 	if (gx > maxR) gx = (uint32_t)maxR;
 	if (gx < 1) gx = 1;
-	const dim3 grid(gx, n_frames);
+	// many small frames (8192 x 320x240: 7 regions each): one row of gx workgroups per frame would launch a quarter of a million
+	// one-wave workgroups of which most find nothing to do; the rows stride over the frames instead
+	uint32_t gy = n_frames;
+	if ((size_t)gx * gy > 131072u) {
+		const uint32_t want = (uint32_t)(((size_t)stride / 8 + FRB - 1) / FRB) + 1;   // regions of a frame whose stream is an eighth of the worst case
+		if (gx > want) gx = want;
+		if ((size_t)gx * gy > 131072u) gy = 131072u / gx;
+	}
+	const dim3 grid(gx, gy);
 	if (bitmap) CK(hipMemsetAsync(A.tidx, 0xFF, (size_t)n_frames * (tpfd + 1) * 4, s));   // TIDX_NONE
+	CK(hipMemsetAsync(A.nbad, 0, 4, s));
 	if (robust_only) {                                         // debugging aid: every frame through the robust kernels (bitmap form)
 		CK(hipMemsetD32Async((hipDeviceptr_t)A.fstate, (int)FS_BAD, n_frames, s));
+		CK(hipMemsetD32Async((hipDeviceptr_t)A.nbad, (int)n_frames, 1, s));
 	} else {
 		if (c->mode512) hipLaunchKernelGGL(k_fp_walk<true>, grid, dim3(64), 0, s, A);
 		else            hipLaunchKernelGGL(k_fp_walk<false>, grid, dim3(64), 0, s, A);
@@ -2879,19 +2900,19 @@ static int parse_launch(agmv_hip_ctx* c, const uint8_t* d_bits, size_t stride, c
 		uint32_t ge = gx;                                      // (a quarter / an eighth of it: 0.179 / 0.188 against 0.169 ms per 256 frames)
 		if (getenv("AGMV_EXPAND_GX")) ge = (uint32_t)atoi(getenv("AGMV_EXPAND_GX"));   // tuning aid
 		if (ge < 1) ge = 1;
-		hipLaunchKernelGGL(k_fp_expand, dim3(ge, n_frames), dim3(64), 0, s, A);
+		hipLaunchKernelGGL(k_fp_expand, dim3(ge, n_frames), dim3(64), 0, s, A);   // (one row per frame)
 		CK(hipGetLastError());
-		return parse_launch_robust(c, d_bits, stride, d_bpos, n_frames, nblk, d_offsets, d_nentered, ws_frames, A.fstate, s);
+		return parse_launch_robust(c, d_bits, stride, d_bpos, n_frames, nblk, d_offsets, d_nentered, ws_frames, A.fstate, s, nullptr, 0, A.nbad);
 	}
 	// bitmap form: the frames that could not be proven get their entry BITS from the robust kernels, are counted and
 	// numbered like the proven ones (k_fp_recount), then every frame's tile entries are looked up
-	if (parse_launch_robust(c, d_bits, stride, d_bpos, n_frames, nblk, nullptr, d_nentered, ws_frames, A.fstate, s, A.vm, A.maxR)) return -1;
-	hipLaunchKernelGGL(k_fp_recount, dim3(n_frames < 64u ? n_frames : 64u), dim3(64), 0, s, A);
+	if (parse_launch_robust(c, d_bits, stride, d_bpos, n_frames, nblk, nullptr, d_nentered, ws_frames, A.fstate, s, A.vm, A.maxR, A.nbad)) return -1;
+	hipLaunchKernelGGL(k_fp_recount, dim3(n_frames < 1024u ? n_frames : 1024u), dim3(64), 0, s, A);
 	CK(hipGetLastError());
 	uint32_t gt = gx / 2 ? gx / 2 : 1;
 	if (getenv("AGMV_TILES_GX")) gt = (uint32_t)atoi(getenv("AGMV_TILES_GX"));   // tuning aid
 	if (gt < 1) gt = 1;
-	hipLaunchKernelGGL(k_fp_tiles, dim3(gt, n_frames), dim3(64), 0, s, A);
+	hipLaunchKernelGGL(k_fp_tiles, dim3(gt, gy), dim3(64), 0, s, A);
 	CK(hipGetLastError());
 	return 0;
 }

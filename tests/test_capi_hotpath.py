@@ -84,6 +84,15 @@ class Player:
         C.c_void_p.from_address(track + 16).value = libc.calloc(2 * self.L.AGMV_GetAudioSize(self.a) + 64, 2)   # ->pcm (room for the chunks the script decodes twice)
         C.c_void_p.from_address(track + 24).value = None                      # ->pcm8
         C.c_ulong.from_address(track + 8).value = 0                           # ->start_point
+        # the reference's CreateAGMV mallocs img_data / iframe / the bitstream buffer without clearing them (src/agmv_utils.c:332-369);
+        # blocks a frame does not reach keep what is there, so in a process whose heap is no longer fresh the reference
+        # would start from garbage.  Both objects start from zeroes (ours callocs; SURVEY 8c freezes the UB to zero pages).
+        npx = 320 * 240
+        for off in (4200, 4208):                                              # agmv->frame, agmv->iframe
+            fr = C.c_void_p.from_address(self.a + off).value
+            C.memset(C.c_void_p.from_address(fr + 16).value, 0, npx * C.sizeof(C.c_ulong))      # ->img_data
+        bs = C.c_void_p.from_address(self.a + 4192).value                     # agmv->bitstream
+        C.memset(C.c_void_p.from_address(bs).value, 0, C.c_ulong.from_address(bs + 8).value)    # ->data[0 .. len)
         chunk = C.c_void_p.from_address(self.a + 4184).value                  # agmv->audio_chunk: the reference's CreateAGMV leaves
         C.c_void_p.from_address(chunk + 16).value = None                      # its pointers uninitialised and DestroyAGMV frees them
         C.c_void_p.from_address(chunk + 24).value = None

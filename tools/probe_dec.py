@@ -4,7 +4,7 @@ R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, "tests"))
 import synth as S
 from libagmv_amd import AgmvHip
-W, H, T = 1920, 1080, int(os.environ.get("T", "256"))
+W, H, T = int(os.environ.get("W", "1920")), int(os.environ.get("H", "1080")), int(os.environ.get("T", "256"))
 hip = AgmvHip(0, lib=os.environ.get("PROBE_LIB"))
 p0, p1 = S.content_palettes([S.synth_frame(W, H, t) for t in range(2)])
 hip.set_palette(p0, p1, True); hip.enable_timing(True)
