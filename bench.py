@@ -62,10 +62,10 @@ def parse_args():
 
 def workload(args):
     if args.workload == "c3":
-        return dict(name="c3: 1024-frame 1920x1080 agmv_synth_v1, HIGH_QUALITY palette, OPT_III (512 colours)",
+        return dict(name="c3: %d-frame 1920x1080 agmv_synth_v1, HIGH_QUALITY palette, OPT_III (512 colours)" % (args.frames or 1024),
                     W=1920, H=1080, T=args.frames or 1024, quality=1, pdifs=False)
     if args.workload == "c5":
-        return dict(name="c5: 1280x720 agmv_synth_v1 stream, HIGH_QUALITY palette, OPT_III",
+        return dict(name="c5: %d-frame 1280x720 agmv_synth_v1 stream, HIGH_QUALITY palette, OPT_III" % (args.frames or 1024),
                     W=1280, H=720, T=args.frames or 1024, quality=1, pdifs=False)
     return dict(name="c2: 212-frame 320x240 agmv_synth_v1 -> 156 encoded frames (AGMV_EncodeAGMV light PDIFS), "
                      "LOW_QUALITY palette, OPT_III", W=320, H=240, T=args.frames or 212, quality=3, pdifs=True)
