@@ -42,7 +42,9 @@ CASES = ["agmv_opt3_low_lzss_160x128", "agmv_opt1_mid_lzss_160x128", "agmv_opt2_
          # (121x81 read as 120x80, heavy PDIFS) and a 1280x720 OPT_III clip through AGMV_EncodeAGMV
          "c4_agmv_gba1_low_lzss_1920x1080", "c5_agmv_opt3_low_lzss_1280x720",
          # config 4 at 256 source frames of 1080p (tests/golden/make_golden_r3.py): 127 encoded GBA frames, 1.6 GB of BMPs
-         "c4_256_agmv_gba1_low_lzss_1920x1080"]
+         "c4_256_agmv_gba1_low_lzss_1920x1080",
+         # config 5's shape at 48 source frames of 1280x720 (33 encoded frames; the reference's own LZSS needs ~10 s per frame)
+         "c5_48_agmv_opt3_low_lzss_1280x720"]
 
 
 @pytest.mark.parametrize("name", CASES)
