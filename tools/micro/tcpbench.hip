@@ -51,6 +51,11 @@ __global__ __launch_bounds__(256) void k_pat(const uint32_t* __restrict__ src, s
 		case 21: line = q; in = (l4 >> 1) * 4; break;                      // {0,0,4,4}: two addresses 8 bytes apart
 		case 22: line = q; in = l4 == 3 ? 1 : 0; break;                    // {0,0,0,1}
 		case 23: line = q; in = l4 == 3 ? 8 : 0; break;                    // {0,0,0,8}: three lanes one address, one lane 16 bytes on
+		case 24: line = q; in = (q & 1) ? (l4 >> 1) * 4 : l4; break;           // even quads {0,1,2,3} (fast), odd quads {0,0,4,4} (slow)
+		case 25: line = q; in = (q & 3) == 0 ? (l4 >> 1) * 4 : l4; break;      // one slow quad per 16 lanes
+		case 26: line = q; in = q == 0 ? (l4 >> 1) * 4 : l4; break;            // one slow quad per wave
+		case 27: line = q; in = lane >= 32 ? (l4 >> 1) * 4 : l4; break;        // lanes 0-31 fast, 32-63 slow
+		case 28: line = q; in = (q & 1) ? l4 * 16 : l4; break;                 // even quads fast, odd quads spread over the line
 		default: line = 0; in = 0;
 		}
 		line = (line + 5u * (uint32_t)k + (salt & 1u)) & 127u;             // 128 lines = 16 KB footprint
@@ -96,7 +101,7 @@ template <int PAT, int NLK, int WIDE, int LMASK = 0> static float run(const uint
 	return best;
 }
 
-int main()
+int main(int argc, char** argv)
 {
 	hipDeviceProp_t prop; CK(hipGetDeviceProperties(&prop, 0));
 	const int ncu = prop.multiProcessorCount;
@@ -109,6 +114,17 @@ int main()
 		printf("%-58s N=%2d w=%2d  %6.1f ns/item/CU  %5.2f TB/s\n", name, N, w, ms * 1e6 / (nitems / (double)ncu), bytes / ms / 1e9); } fflush(stdout); } while (0)
 #define RM(P, N, M, name) do { for (int w : {16}) { float ms = run<P, N, 0, M>(src, nitems, lut, sink, ncu, w); \
 		printf("%-58s N=%2d w=%2d  %6.1f ns/item/CU  %5.2f TB/s\n", name, N, w, ms * 1e6 / (nitems / (double)ncu), bytes / ms / 1e9); } fflush(stdout); } while (0)
+	if (argc > 1) {                                                    // mixed instructions: is the fast path decided per quad or per instruction?
+		RM(0, 0, 0, "no look-ups");
+		RM(14, 16, 0, "P14 every quad {0,1,2,3} (fast)");
+		RM(21, 16, 0, "P21 every quad {0,0,4,4} (slow)");
+		RM(24, 16, 0, "P24 even quads fast, odd quads slow");
+		RM(28, 16, 0, "P28 even quads fast, odd quads over the line");
+		RM(25, 16, 0, "P25 one slow quad per 16 lanes");
+		RM(26, 16, 0, "P26 one slow quad per wave");
+		RM(27, 16, 0, "P27 lanes 0-31 fast, 32-63 slow");
+		return 0;
+	}
 	RM(0, 0, 0, "no look-ups");
 	RM(0, 16, 0, "P0 all lanes one address");
 	RM(1, 16, 0, "P1 one line, 64 entries (u16 lane)");
