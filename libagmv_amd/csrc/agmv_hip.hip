@@ -1298,9 +1298,6 @@ __global__ __launch_bounds__(64) void k_parse_emit(ParseArgs A)
 constexpr int FROW = FC / 4 + 1;        // LDS dwords per piece (odd stride: no bank conflicts between the lanes' pieces)
 constexpr uint32_t FX_SLIDE = 64u, FX_END = 65u, FX_UNSET = 66u, FX_MERGE = 128u;
 constexpr int FP_REPAIRS = 24;          // regions of one frame walked again (serially, by the frame's wave) before the frame is given up
-#ifndef FP_NBATCH
-#define FP_NBATCH 1                     // lanes waiting at a NORMAL block before their lengths are computed together (1 / 4 / 8 / 16 / 32 measured the same: synth 0.185-0.191, NORMAL-heavy 0.400-0.419 ms per 256 frames)
-#endif
 constexpr int FP_LDS = 64 * FROW + 1;   // (+1: lane 63's look at "the piece behind" stays inside)
 
 struct FpArgs {
@@ -1373,21 +1370,32 @@ __device__ __forceinline__ void fp_walk_region(const FpArgs& A, uint32_t* s_b, u
 	}
 	const long lim_l = (long)bpos - cb;                        // a block of this piece counts when it ends at or before this offset
 	const int lim = lim_l > 1000 ? 1000 : (lim_l < -1000 ? -1000 : (int)lim_l);
+	unsigned long long safe;                                   // positions at which any COPY / FILL ends at or before bpos
 	{
 		const long nv = lim_l + 1;                             // bytes of the piece at positions <= bpos: only those are nodes
 		const unsigned long long ok = nv <= 0 ? 0ull : (nv < 64 ? (1ull << nv) - 1ull : ~0ull);
 		F &= ok;
-		// run skipping (below) only takes blocks that end at or before bpos: COPY at positions < bpos, two-byte FILL at positions < bpos - 1
-		C &= ok >> 1;
-		L &= ok >> 2;
+		safe = ok >> 3;
 	}
 	const bool more = lim >= FC;                               // the stream goes on behind this piece
 	unsigned long long En = 0;                                 // escape codes of the piece behind (a NORMAL body spills <= 33 bytes)
-	if (M512) {
-		const uint32_t lo = (uint32_t)__shfl_down((int)(uint32_t)E, 1, 64), hi = (uint32_t)__shfl_down((int)(uint32_t)(E >> 32), 1, 64);
-		En = lane < 63 ? ((unsigned long long)hi << 32 | lo) : 0ull;
-		L &= ~((E >> 1) | (En << 63));                         // FILL whose index byte is not an escape code: two bytes
+	unsigned long long D;
+	{
+		unsigned long long L3 = 0;                             // FILLs whose index byte is an escape code: three bytes (L: the two-byte ones)
+		if (M512) {
+			const uint32_t lo = (uint32_t)__shfl_down((int)(uint32_t)E, 1, 64), hi = (uint32_t)__shfl_down((int)(uint32_t)(E >> 32), 1, 64);
+			En = lane < 63 ? ((unsigned long long)hi << 32 | lo) : 0ull;
+			L3 = L & ((E >> 1) | (En << 63));
+			L &= ~L3;
+		}
+		D = (F & ~(C | L | L3)) | (F & ((L << 1) | (L3 << 1) | (L3 << 2))) | (F & ~safe);
 	}
+	// A STRETCH of the stream in which every flag byte is a COPY or a FILL that ends at or before bpos, and no flag-valued byte
+	// lies inside the body of one of them, is walked in ONE step: the chain through it is exactly its flag bytes (a block's
+	// successor is entered right behind its body and slides to the next flag byte -- which is the next flag byte of the stretch).
+	// D = where a stretch must end: NORMAL blocks (their length needs the escape count), flag-valued bytes inside the body of a
+	// FILL (which of the two is a block depends on the chain), blocks too close to bpos.  Conservative on purpose: a D bit
+	// only hands the block at that byte to the one-block step below.  (D is computed above, where the three-byte FILLs are known.)
 	const int first = forced != FX_UNSET ? FH : 0;              // first lane that walks (its entry: forced, or speculative)
 	const bool walker = lane >= first && lane < 63 && cb >= 0;
 	const uint32_t* mine = s_b + lane * FROW;
@@ -1417,56 +1425,69 @@ __device__ __forceinline__ void fp_walk_region(const FpArgs& A, uint32_t* s_b, u
 				}
 			}
 		}
-		// The walk, written without divergent branches (selects on every lane).  One step takes a whole RUN of blocks of
-		// the same kind when it can: consecutive COPY bytes, or two-byte FILLs back to back -- at most 31 bytes of them, and
-		// only up to where the old walk has a node (the merge is found by the next step).
+		// The walk, written without divergent branches (selects on every lane).  One step takes a whole stretch (see D above;
+		// it also ends where the old walk has a node) and then, if the chain arrives at a D byte, the one block there.
 		uint32_t wres = FX_UNSET;
 		for (;;) {
 			if (__ballot(go) == 0) break;
-			const uint32_t q32 = (uint32_t)(Q >> q), c32 = (uint32_t)(C >> q), l32 = (uint32_t)(L >> q);   // 32-byte windows from q
-			const bool merged = go && (q32 & 1u);
-			wres = merged ? FX_MERGE + q : wres;
-			go = go && !merged;
-			const uint32_t d0 = mine[q >> 2], d1 = mine[(q >> 2) + 1];
-			const uint32_t two = __builtin_amdgcn_alignbyte((q >> 2) == 15u ? behind : d1, d0, q & 3u);
-			const uint32_t t = two & 0xFFu;
-			const bool isN = t == NORMAL_FLAG, isC = t == COPY_FLAG;
-			// blocks the step takes: a run of COPYs / of two-byte FILLs (bit 31 / bit 30 stop the count), else one
-			const uint32_t oldn = q32 & ~1u;                       // old nodes behind q
-			const uint32_t rc = (uint32_t)__builtin_ctz(~c32 | oldn | 0x80000000u);
-			const uint32_t rl = (uint32_t)__builtin_ctz(((~l32 | oldn) & 0x55555555u) | 0x40000000u) >> 1;
-			uint32_t len1 = isC ? 1u : 2u + ((M512 && ((two >> 8) & 0x7Fu) == 127u) ? 1u : 0u);   // length of the block at q
-			uint32_t nrun = 1, qm = 1;                             // blocks taken; their nodes as a mask from q
-			if (isC && rc > 1u) { nrun = rc; qm = (1u << rc) - 1u; }
-			if (!isC && !isN && rl > 1u) { nrun = rl; qm = ((1u << (2u * rl)) - 1u) & 0x55555555u; }
-			// NORMAL lengths (16 dependent steps), for all the lanes that wait at one (FP_NBATCH: or only once enough of them do)
-			const unsigned long long pm = __ballot(go && isN), am = __ballot(go && !isN);
-			const bool doN = pm != 0 && (am == 0 || __popcll(pm) >= FP_NBATCH);
-			if (doN) {
-				uint32_t len = 16;
-				if (M512) {
-					const uint32_t q1 = q + 1u;
-					const uint32_t m = (uint32_t)((q1 < 64u ? E >> q1 : 0ull) | (En << (63u - q)));
-					uint32_t pos = 0;
-#pragma unroll
-					for (int i = 0; i < 16; i++) pos += 1u + ((m >> pos) & 1u);
-					len = pos;
-				}
-				if (isN) len1 = 1u + len;
+			{
+				const bool merged = go && ((Q >> q) & 1ull);
+				wres = merged ? FX_MERGE + q : wres;
+				go = go && !merged;
 			}
-			const uint32_t e = q + nrun * len1;                    // (runs: every block has the length of the first)
-			const bool adv = go && (!isN || doN);
-			const bool over = (int)e > lim;                        // entered, not counted: the chain ends
-			const bool cnt = adv && !over;
-			const unsigned long long qbits = (unsigned long long)qm << q;
-			Qw |= cnt ? qbits : 0ull;
-			Vw |= cnt ? qbits << len1 : 0ull;                      // an entry behind every node taken; those at byte 64 and beyond belong to the next piece
-			const unsigned long long m = F >> (e & 63u);
-			const bool inside = cnt && e < 64u && m != 0;
-			const uint32_t stop = over ? FX_END : (e >= 64u ? e - 64u : (more ? FX_SLIDE : FX_END));
-			wres = (adv && !inside) ? stop : wres;
-			q = inside ? e + ctz64(m) : q;
-			go = go && (!adv || inside);
+			const unsigned long long hiq = ~0ull << q;             // bytes >= q
+			const unsigned long long dq = (D & hiq) | (Q & (hiq << 1));
+			const uint32_t d = dq ? ctz64(dq) : 64u;
+			const bool str = go && d != q;
+			if (__ballot(str) != 0) {                              // (wave-uniform: NORMAL-heavy streams rarely come here)
+				const unsigned long long nodes = F & hiq & (d >= 64u ? ~0ull : ~(~0ull << d));
+				const uint32_t last = 63u - (uint32_t)__builtin_clzll(nodes | 1ull);
+				const uint32_t e = last + (((C >> last) & 1ull) ? 1u : (((L >> last) & 1ull) ? 2u : 3u));
+				Qw |= str ? nodes : 0ull;
+				// an entry behind every node (three-byte FILLs: what is neither COPY nor two-byte FILL); those at byte 64 and beyond belong to the next piece
+				Vw |= str ? ((nodes & C) << 1) | ((nodes & L) << 2) | ((nodes & ~(C | L)) << 3) : 0ull;
+				const unsigned long long m = F >> (e & 63u);
+				const bool inside = e < 64u && m != 0;
+				const uint32_t stop = e >= 64u ? e - 64u : (more ? FX_SLIDE : FX_END);
+				wres = (str && !inside) ? stop : wres;
+				const uint32_t p = e + ctz64(m | (1ull << 63));
+				const bool arrived = str && inside;
+				const bool merged = arrived && ((Q >> (p & 63u)) & 1ull);
+				wres = merged ? FX_MERGE + p : wres;
+				q = arrived ? p : q;
+				go = go && (!str || (inside && !merged));
+			}
+			const bool sing = go && ((D >> q) & 1ull);
+			if (__ballot(sing) != 0) {
+				const uint32_t d0 = mine[q >> 2], d1 = mine[(q >> 2) + 1];
+				const uint32_t two = __builtin_amdgcn_alignbyte((q >> 2) == 15u ? behind : d1, d0, q & 3u);
+				const uint32_t t = two & 0xFFu;
+				const bool isN = t == NORMAL_FLAG, isC = t == COPY_FLAG;
+				uint32_t l1 = isC ? 1u : 2u + ((M512 && ((two >> 8) & 0x7Fu) == 127u) ? 1u : 0u);
+				if (__ballot(sing && isN) != 0) {                  // NORMAL lengths: 16 dependent steps on the escape mask
+					uint32_t len = 16;
+					if (M512) {
+						const uint32_t q1 = q + 1u;
+						const uint32_t m = (uint32_t)((q1 < 64u ? E >> q1 : 0ull) | (En << (63u - q)));
+						uint32_t pos = 0;
+#pragma unroll
+						for (int i = 0; i < 16; i++) pos += 1u + ((m >> pos) & 1u);
+						len = pos;
+					}
+					if (isN) l1 = 1u + len;
+				}
+				const uint32_t e = q + l1;
+				const bool over = (int)e > lim;                    // entered, not counted: the chain ends
+				const bool cnt = sing && !over;
+				Qw |= cnt ? 1ull << q : 0ull;
+				Vw |= cnt ? (1ull << q) << l1 : 0ull;
+				const unsigned long long m = F >> (e & 63u);
+				const bool inside = cnt && e < 64u && m != 0;
+				const uint32_t stop = over ? FX_END : (e >= 64u ? e - 64u : (more ? FX_SLIDE : FX_END));
+				wres = (sing && !inside) ? stop : wres;
+				q = inside ? e + ctz64(m) : q;
+				go = go && (!sing || inside);
+			}
 		}
 		if (need && wres != FX_UNSET) {
 			if (wres >= FX_MERGE) {
@@ -1490,7 +1511,7 @@ __device__ __forceinline__ void fp_walk_region(const FpArgs& A, uint32_t* s_b, u
 }
 
 template <bool M512>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_fp_walk(FpArgs A)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void k_fp_walk(FpArgs A)
 {
 	__shared__ uint32_t s_b[FP_LDS];
 	const int lane = threadIdx.x;
