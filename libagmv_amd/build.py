@@ -22,14 +22,51 @@ def _stale(target, sources):
     return any(os.path.getmtime(s) > t for s in sources)
 
 
-def _compile(cmd, target, verbose):
-    """compile to a temporary name, then rename: a concurrent reader never sees a half-written library"""
+def _scratch_users(remarks):
+    """kernels with a non-zero ScratchSize in hipcc's -Rpass-analysis=kernel-resource-usage remarks"""
+    bad, name = [], None
+    for line in remarks.splitlines():
+        if "Function Name:" in line:
+            name = line.split("Function Name:")[1].split("[")[0].strip()
+        elif "ScratchSize [bytes/lane]:" in line:
+            n = int(line.split("ScratchSize [bytes/lane]:")[1].split("[")[0])
+            if n:
+                bad.append("%s (%d bytes/lane)" % (name, n))
+    return bad
+
+
+def _compile(cmd, target, verbose, no_scratch=False):
+    """compile to a temporary name, then rename: a concurrent reader never sees a half-written library.
+    no_scratch: refuse a device build in which any kernel spills to scratch memory (round 3: a 12-byte spill in k_fp_walk
+    gave sporadically wrong block counts on the MI355X; every kernel of this library is sized to stay in registers)"""
     tmp = target + ".tmp.%d" % os.getpid()
     cmd = [tmp if c == target else c for c in cmd]
+    if no_scratch:
+        cmd = cmd[:1] + ["-Rpass-analysis=kernel-resource-usage"] + cmd[1:]
     if verbose:
         print(" ".join(cmd))
     try:
-        subprocess.run(cmd, check=True)
+        if no_scratch:
+            r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, universal_newlines=True)
+            keep, in_remark = [], False                      # the remarks (and the source lines quoted under them) are not shown
+            for l in r.stderr.splitlines():
+                if "kernel-resource-usage" in l:
+                    in_remark = True
+                elif in_remark and l.lstrip()[:1] in ("|", "") or in_remark and l.split("|")[0].strip().isdigit():
+                    pass
+                else:
+                    in_remark = False
+                    keep.append(l)
+            rest = "\n".join(keep)
+            if rest.strip():
+                sys.stderr.write(rest + "\n")
+            if r.returncode:
+                raise subprocess.CalledProcessError(r.returncode, cmd)
+            bad = _scratch_users(r.stderr)
+            if bad:
+                raise RuntimeError("kernels spilling to scratch memory: " + ", ".join(bad))
+        else:
+            subprocess.run(cmd, check=True)
         os.replace(tmp, target)
     finally:
         if os.path.exists(tmp):
@@ -51,7 +88,7 @@ def _build(force=False, verbose=False):
     hdrs = glob.glob(os.path.join(ROOT, "include", "*.h"))
     hip_so = os.path.join(HERE, "libagmv_hip.so")
     if force or _stale(hip_so, [hip_src] + hdrs):
-        _compile([HIPCC, "--offload-arch=" + ARCH, "-O3", "-fPIC", "-shared", "-std=c++17", hip_src, "-o", hip_so], hip_so, verbose)
+        _compile([HIPCC, "--offload-arch=" + ARCH, "-O3", "-fPIC", "-shared", "-std=c++17", hip_src, "-o", hip_so], hip_so, verbose, no_scratch=True)
     c_srcs = sorted(glob.glob(os.path.join(CSRC, "*.c")))
     if c_srcs:
         host_so = os.path.join(HERE, "libagmv.so")

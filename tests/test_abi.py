@@ -50,3 +50,14 @@ def test_example_program_builds_against_the_drop_in_headers(tmp_path):
                     "-L" + os.path.join(ROOT, "libagmv_amd"), "-lagmv", "-lagmv_hip",
                     "-Wl,-rpath," + os.path.join(ROOT, "libagmv_amd"), "-o", exe], check=True)
     assert os.path.exists(exe)
+
+
+def test_build_refuses_kernels_that_spill():
+    """the device build is refused when hipcc reports scratch use for any kernel (libagmv_amd/build.py): the parser of its remarks"""
+    from libagmv_amd import build as B
+    sample = ("a.hip:185:1: remark: Function Name: k_one [-Rpass-analysis=kernel-resource-usage]\n"
+              "a.hip:185:1: remark:     ScratchSize [bytes/lane]: 0 [-Rpass-analysis=kernel-resource-usage]\n"
+              "a.hip:209:1: remark: Function Name: k_two [-Rpass-analysis=kernel-resource-usage]\n"
+              "a.hip:209:1: remark:     ScratchSize [bytes/lane]: 12 [-Rpass-analysis=kernel-resource-usage]\n")
+    assert B._scratch_users(sample) == ["k_two (12 bytes/lane)"]
+    assert B._scratch_users("") == []
