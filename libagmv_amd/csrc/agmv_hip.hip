@@ -1349,24 +1349,27 @@ __device__ __forceinline__ void fp_walk_region(const FpArgs& A, uint32_t* s_b, u
 		// bit 7 of every byte that is 0 (exact per byte)
 		auto zero7 = [](uint32_t v) -> uint32_t { return ~(((v & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | v) & 0x80808080u; };
 		// the four bits (bit 7 of each byte) of two dwords as one byte: a dot product of the bytes {0, 0x80} with the weights
-		// 1, 2, 4, 8 / 16, 32, 64, 128 is 128 x that byte (v_dot4_u32_u8: two instructions where shifts and ors take a dozen)
-		auto pair8 = [](uint32_t z0, uint32_t z1) -> uint32_t {
-			return __builtin_amdgcn_udot4(z1, 0x80402010u, __builtin_amdgcn_udot4(z0, 0x08040201u, 0u, false), false) >> 7;
+		// 1, 2, 4, 8 / 16, 32, 64, 128 is 128 x that byte (v_dot4_u32_u8: two instructions where shifts and ors take a dozen).
+		// FILL (0x4E) and COPY (0x5E) differ in bit 4 only: one zero test finds both, bit 4 tells them apart; the packed byte of a
+		// pair of dwords comes out of the dot products times 128 and goes to its place with ONE shift
+		uint32_t f2[2] = {0, 0}, c2[2] = {0, 0}, lc2[2] = {0, 0}, e2[2] = {0, 0};
+		auto place = [](uint32_t acc, uint32_t x128, int sh) -> uint32_t { return acc | (sh == 0 ? x128 >> 7 : x128 << (sh - 7)); };
+		auto pair128 = [](uint32_t z0, uint32_t z1) -> uint32_t {
+			return __builtin_amdgcn_udot4(z1, 0x80402010u, __builtin_amdgcn_udot4(z0, 0x08040201u, 0u, false), false);
 		};
-		uint32_t f2[2] = {0, 0}, c2[2] = {0, 0}, l2[2] = {0, 0}, e2[2] = {0, 0};
 #pragma unroll
 		for (int j = 0; j < 16; j += 2) {
 			const uint32_t w0 = s_b[lane * FROW + j], w1 = s_b[lane * FROW + j + 1];
-			const uint32_t zl0 = zero7(w0 ^ 0x4E4E4E4Eu), zc0 = zero7(w0 ^ 0x5E5E5E5Eu), zn0 = zero7(w0 ^ 0x2F2F2F2Fu);
-			const uint32_t zl1 = zero7(w1 ^ 0x4E4E4E4Eu), zc1 = zero7(w1 ^ 0x5E5E5E5Eu), zn1 = zero7(w1 ^ 0x2F2F2F2Fu);
+			const uint32_t zlc0 = zero7((w0 | 0x10101010u) ^ 0x5E5E5E5Eu), zn0 = zero7(w0 ^ 0x2F2F2F2Fu);
+			const uint32_t zlc1 = zero7((w1 | 0x10101010u) ^ 0x5E5E5E5Eu), zn1 = zero7(w1 ^ 0x2F2F2F2Fu);
 			const int h = j >> 3, sh = 4 * (j & 7);
-			l2[h] |= pair8(zl0, zl1) << sh;
-			c2[h] |= pair8(zc0, zc1) << sh;
-			f2[h] |= pair8(zl0 | zc0 | zn0, zl1 | zc1 | zn1) << sh;
-			if (M512) e2[h] |= pair8(((w0 & 0x7F7F7F7Fu) + 0x01010101u) & 0x80808080u, ((w1 & 0x7F7F7F7Fu) + 0x01010101u) & 0x80808080u) << sh;   // (byte & 0x7f) == 127
+			lc2[h] = place(lc2[h], pair128(zlc0, zlc1), sh);
+			c2[h] = place(c2[h], pair128(zlc0 & (w0 << 3), zlc1 & (w1 << 3)), sh);
+			f2[h] = place(f2[h], pair128(zlc0 | zn0, zlc1 | zn1), sh);
+			if (M512) e2[h] = place(e2[h], pair128(((w0 & 0x7F7F7F7Fu) + 0x01010101u) & 0x80808080u, ((w1 & 0x7F7F7F7Fu) + 0x01010101u) & 0x80808080u), sh);   // (byte & 0x7f) == 127
 		}
 		F = (unsigned long long)f2[1] << 32 | f2[0]; C = (unsigned long long)c2[1] << 32 | c2[0];
-		L = (unsigned long long)l2[1] << 32 | l2[0]; E = (unsigned long long)e2[1] << 32 | e2[0];
+		L = ((unsigned long long)lc2[1] << 32 | lc2[0]) ^ C; E = (unsigned long long)e2[1] << 32 | e2[0];
 	}
 	const long lim_l = (long)bpos - cb;                        // a block of this piece counts when it ends at or before this offset
 	const int lim = lim_l > 1000 ? 1000 : (lim_l < -1000 ? -1000 : (int)lim_l);
