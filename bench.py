@@ -288,7 +288,7 @@ def main():
         torch.cuda.synchronize()
         g0 = time.perf_counter()
         from libagmv_amd import shard
-        gathered = shard.gather_bitstreams(dist, sizes, shard.pack_frames(out, sizes), dst=0)
+        gathered = shard.gather_bitstreams(dist, sizes, shard.pack_frames(out, sizes, hip=hip), dst=0)
         if rank == 0:
             assert sum(int(s.numel()) for s, _ in gathered) == (T if args.scaling == "strong" else world * n_enc)
         torch.cuda.synchronize()

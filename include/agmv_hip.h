@@ -175,6 +175,21 @@ int agmv_hip_decode_frames(agmv_hip_ctx* ctx, const uint8_t* h_bits, size_t bits
                            uint32_t first_frame_count, uint32_t* h_pix_out,
                            const uint32_t* h_prev_frame, const uint32_t* h_prev_iframe);
 
+/* -- exchange step of the GOP-sharded encoder (the reference is single-process: its "gather" is the frame
+ * loop of AGMV_EncodeAGMV appending chunk after chunk, src/agmv_encode.c:3610-3612) --------------------------------
+ * A rank's bitstreams travel as ONE contiguous message: the used bytes of every slab row back to back.
+ * agmv_hip_pack_frames_dev:   d_slab [n_frames][stride] + d_sizes[n_frames] (as agmv_hip_encode_frames_dev leaves them)
+ *                             -> d_msg (sum of the sizes bytes; the caller sizes it, e.g. from the sizes it exchanges first)
+ *                             and d_offsets[n_frames + 1] (u64: frame f starts at d_offsets[f]; [n_frames] = the total).
+ * agmv_hip_unpack_frames_dev: the inverse on the receiving rank: d_msg + d_sizes -> rows of a slab (stride a multiple of 4;
+ *                             bytes of a row behind its size are left as they are); d_offsets is scratch of n_frames + 1 u64.
+ * Both are asynchronous on `stream`; what moves the message between the ranks (RCCL send/recv, hipMemcpyPeer, a host
+ * socket) is the caller's business. */
+int agmv_hip_pack_frames_dev(agmv_hip_ctx* ctx, const uint8_t* d_slab, size_t stride, const uint32_t* d_sizes,
+                             uint32_t n_frames, uint8_t* d_msg, unsigned long long* d_offsets, void* stream);
+int agmv_hip_unpack_frames_dev(agmv_hip_ctx* ctx, const uint8_t* d_msg, const uint32_t* d_sizes, uint32_t n_frames,
+                               uint8_t* d_slab, size_t stride, unsigned long long* d_offsets, void* stream);
+
 /* -- helpers on the caller side of the path -------------------------------------------------*/
 /* canonical synthetic clip agmv_synth_v1: frames t0..t0+n-1 into d_pix */
 int agmv_hip_synth_dev(agmv_hip_ctx* ctx, uint32_t* d_pix, uint32_t w, uint32_t h, uint32_t t0,

@@ -3196,6 +3196,90 @@ extern "C" int agmv_hip_decode_frames(agmv_hip_ctx* c, const uint8_t* h_bits, si
 	return rc;
 }
 
+// ----------------------------------------------------------------------------------------------
+// The exchange step of the GOP-sharded encoder (usize per frame, then the variable-length bitstreams to the
+// root): a rank's frames leave as ONE contiguous message -- the used bytes of every slab row back to back, frame f at
+// offsets[f] -- and arrive in a slab again.  k_pack_scan: offsets = exclusive sums of the sizes (one workgroup);
+// k_pack_copy: rows <-> message, a few workgroups per frame striding over 16 KB chunks.  The unaligned side (the message)
+// is addressed byte-granularly with dword accesses: gfx950 runs global memory in unaligned mode.
+// ----------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_pack_scan(const uint32_t* __restrict__ sizes, uint32_t n, unsigned long long* __restrict__ offsets)
+{
+	__shared__ unsigned long long s_w[4];
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	unsigned long long run = 0;
+	for (uint32_t i0 = 0; i0 < n; i0 += 256) {
+		const uint32_t i = i0 + threadIdx.x;
+		const uint32_t v = i < n ? sizes[i] : 0u;
+		const uint32_t incl = wave_incl_scan(v, lane);
+		if (lane == 63) s_w[wave] = incl;
+		__syncthreads();
+		unsigned long long base = run;
+		for (int k = 0; k < wave; k++) base += s_w[k];
+		if (i < n) offsets[i] = base + incl - v;
+		run += s_w[0] + s_w[1] + s_w[2] + s_w[3];
+		__syncthreads();
+	}
+	if (threadIdx.x == 0) offsets[n] = run;
+}
+
+constexpr uint32_t PACK_CHUNK = 16384;
+template <bool UNPACK>
+__global__ __launch_bounds__(256) void k_pack_copy(uint8_t* __restrict__ slab, unsigned long long stride, const uint32_t* __restrict__ sizes,
+                                                   const unsigned long long* __restrict__ offsets, uint8_t* __restrict__ msg, uint32_t n_frames)
+{
+	for (uint32_t f = blockIdx.y; f < n_frames; f += gridDim.y) {
+		const uint32_t size = sizes[f];
+		uint8_t* row = slab + (size_t)f * stride;                  // 256-byte aligned (agmv_hip_max_usize)
+		uint8_t* m = msg + offsets[f];                             // any alignment
+		for (uint32_t c = blockIdx.x * PACK_CHUNK; c < size; c += gridDim.x * PACK_CHUNK) {
+			const uint32_t len = min(PACK_CHUNK, size - c), nd = len >> 2;
+			for (uint32_t d = threadIdx.x; d < nd; d += 256) {
+				if (UNPACK) *(uint32_t*)(row + c + 4u * d) = *(const u32u*)(m + c + 4u * d);
+				else *(u32u*)(m + c + 4u * d) = *(const uint32_t*)(row + c + 4u * d);
+			}
+			const uint32_t t = 4u * nd + threadIdx.x;              // the <= 3 bytes behind the last whole dword
+			if (t < len) {
+				if (UNPACK) row[c + t] = m[c + t]; else m[c + t] = row[c + t];
+			}
+		}
+	}
+}
+
+static int pack_launch(agmv_hip_ctx* c, bool unpack, uint8_t* d_slab, size_t stride, const uint32_t* d_sizes, uint32_t n_frames,
+                       uint8_t* d_msg, unsigned long long* d_offsets, hipStream_t s)
+{
+	if (!d_slab || !d_sizes || !d_msg || !d_offsets) { snprintf(g_err, sizeof(g_err), "agmv_hip: pack/unpack: NULL argument"); return -1; }
+	if (stride & 3u) { snprintf(g_err, sizeof(g_err), "agmv_hip: pack/unpack: the slab stride must be a multiple of 4 (agmv_hip_max_usize is)"); return -1; }
+	hipLaunchKernelGGL(k_pack_scan, dim3(1), dim3(256), 0, s, d_sizes, n_frames, d_offsets);
+	CK(hipGetLastError());
+	uint32_t gx = (uint32_t)((stride / 8 + PACK_CHUNK - 1) / PACK_CHUNK);   // chunks of a frame whose stream is an eighth of the worst case
+	if (gx < 1) gx = 1;
+	uint32_t gy = n_frames;
+	if ((size_t)gx * gy > 65536u) { gy = 65536u / gx; if (gy < 1) gy = 1; }
+	if (unpack) hipLaunchKernelGGL(k_pack_copy<true>, dim3(gx, gy), dim3(256), 0, s, d_slab, (unsigned long long)stride, d_sizes, d_offsets, d_msg, n_frames);
+	else        hipLaunchKernelGGL(k_pack_copy<false>, dim3(gx, gy), dim3(256), 0, s, d_slab, (unsigned long long)stride, d_sizes, d_offsets, d_msg, n_frames);
+	CK(hipGetLastError());
+	(void)c;
+	return 0;
+}
+
+extern "C" int agmv_hip_pack_frames_dev(agmv_hip_ctx* c, const uint8_t* d_slab, size_t stride, const uint32_t* d_sizes, uint32_t n_frames,
+                                        uint8_t* d_msg, unsigned long long* d_offsets, void* stream)
+{
+	if (need_ctx(c, false)) return -1;
+	if (n_frames == 0) return 0;
+	return pack_launch(c, false, (uint8_t*)d_slab, stride, d_sizes, n_frames, d_msg, d_offsets, (hipStream_t)stream);
+}
+
+extern "C" int agmv_hip_unpack_frames_dev(agmv_hip_ctx* c, const uint8_t* d_msg, const uint32_t* d_sizes, uint32_t n_frames,
+                                          uint8_t* d_slab, size_t stride, unsigned long long* d_offsets, void* stream)
+{
+	if (need_ctx(c, false)) return -1;
+	if (n_frames == 0) return 0;
+	return pack_launch(c, true, d_slab, stride, d_sizes, n_frames, (uint8_t*)d_msg, d_offsets, (hipStream_t)stream);
+}
+
 extern "C" int agmv_hip_synth_dev(agmv_hip_ctx* c, uint32_t* d_pix, uint32_t w, uint32_t h, uint32_t t0, uint32_t n_frames,
                                   uint64_t seed, void* stream)
 {

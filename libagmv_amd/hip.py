@@ -17,7 +17,7 @@ ABI_SYMBOLS = [
     "agmv_hip_last_error", "agmv_hip_set_palette", "agmv_hip_quantise_dev",
     "agmv_hip_encode_frames_dev", "agmv_hip_encode_frames", "agmv_hip_encode_entries_dev",
     "agmv_hip_encode_entries", "agmv_hip_nearest", "agmv_hip_within2_count", "agmv_hip_parse_frames_dev",
-    "agmv_hip_decode_frames_dev", "agmv_hip_parse_decode_frames_dev", "agmv_hip_decode_bitstreams_dev", "agmv_hip_parse_fallback_frames", "agmv_hip_decode_frames", "agmv_hip_decode_prior_dependent", "agmv_hip_synth_dev",
+    "agmv_hip_decode_frames_dev", "agmv_hip_parse_decode_frames_dev", "agmv_hip_decode_bitstreams_dev", "agmv_hip_pack_frames_dev", "agmv_hip_unpack_frames_dev", "agmv_hip_parse_fallback_frames", "agmv_hip_decode_frames", "agmv_hip_decode_prior_dependent", "agmv_hip_synth_dev",
     "agmv_hip_interp_dev", "agmv_hip_histogram_dev", "agmv_hip_check", "agmv_hip_malloc",
     "agmv_hip_free", "agmv_hip_memcpy_h2d", "agmv_hip_memcpy_d2h", "agmv_hip_memset",
     "agmv_hip_sync", "agmv_hip_enable_timing", "agmv_hip_last_kernel_ms",
@@ -78,6 +78,11 @@ def load_library(path=None):
         L.agmv_hip_decode_bitstreams_dev.restype = C.c_int
     L.agmv_hip_decode_prior_dependent.argtypes = [vp, u32, u32, vp]
     L.agmv_hip_parse_fallback_frames.argtypes = [vp, vp]
+    if path is None or hasattr(L, "agmv_hip_pack_frames_dev"):      # (older builds under tools/variants/ lack it)
+        L.agmv_hip_pack_frames_dev.argtypes = [vp, vp, C.c_size_t, vp, C.c_uint32, vp, vp, vp]
+        L.agmv_hip_pack_frames_dev.restype = C.c_int
+        L.agmv_hip_unpack_frames_dev.argtypes = [vp, vp, vp, C.c_uint32, vp, C.c_size_t, vp, vp]
+        L.agmv_hip_unpack_frames_dev.restype = C.c_int
     L.agmv_hip_parse_fallback_frames.restype = C.c_int
     L.agmv_hip_decode_prior_dependent.restype = C.c_int
     L.agmv_hip_synth_dev.argtypes = [vp, vp, u32, u32, u32, u32, C.c_uint64, vp]
@@ -214,6 +219,32 @@ class AgmvHip:
             n_frames, w, h, first_frame_count, out.data_ptr(),
             prev.data_ptr() if prev is not None else None,
             prev_iframe.data_ptr() if prev_iframe is not None else None, self._stream()))
+        return out
+
+    def pack_frames_dev(self, out, sizes, total=None):
+        """slab [n, stride] u8 + sizes [n] i32 (CUDA) -> (packed u8 [sum(sizes)], offsets i64 [n + 1]); `total` = sum(sizes) if the
+        caller knows it (otherwise one device -> host read)"""
+        import torch
+        n = int(sizes.numel())
+        if total is None:
+            total = int(sizes.sum().item()) if n else 0
+        packed = torch.empty(total, dtype=torch.uint8, device=out.device)
+        offs = torch.zeros(n + 1, dtype=torch.int64, device=out.device)
+        if n and total:                                        # (nothing but empty frames: the offsets are all 0)
+            self._ck(self.L.agmv_hip_pack_frames_dev(self.ctx, out.data_ptr(), out.stride(0), sizes.data_ptr(), n,
+                                                     packed.data_ptr(), offs.data_ptr(), self._stream()))
+        return packed, offs
+
+    def unpack_frames_dev(self, packed, sizes, stride, out=None):
+        """the inverse: packed u8 + sizes [n] i32 (CUDA) -> slab [n, stride] u8 (rows zero behind their size unless `out` is given)"""
+        import torch
+        n = int(sizes.numel())
+        if out is None:
+            out = torch.zeros((n, stride), dtype=torch.uint8, device=packed.device)
+        offs = torch.empty(n + 1, dtype=torch.int64, device=packed.device)
+        if n and packed.numel():
+            self._ck(self.L.agmv_hip_unpack_frames_dev(self.ctx, packed.data_ptr(), sizes.data_ptr(), n, out.data_ptr(), out.stride(0),
+                                                       offs.data_ptr(), self._stream()))
         return out
 
     def parse_fallback_frames(self):

@@ -34,8 +34,12 @@ def gop_ranges(n_frames, world, first_frame_count=0):
     return out
 
 
-def pack_frames(out, sizes):
-    """[n, stride] uint8 slab + [n] sizes -> one contiguous uint8 tensor of the used bytes"""
+def pack_frames(out, sizes, hip=None):
+    """[n, stride] uint8 slab + [n] sizes -> one contiguous uint8 tensor of the used bytes.  With the rank's AgmvHip context and
+    device tensors this is agmv_hip_pack_frames_dev (two kernels); the torch form below (one slice copy per frame) is what the
+    CPU tests of the protocol use"""
+    if hip is not None and out.is_cuda:
+        return hip.pack_frames_dev(out, sizes)[0]
     sz = [int(s) for s in sizes.tolist()]
     if not sz:
         return out.new_empty(0)

@@ -907,3 +907,23 @@ def test_encode_batch_reads_and_writes_entry_plane(torch, hip):
             rest = gpu_encode(torch, hip, frames[1:], first_fc=1, ientries=ient)
             for t, got in enumerate(first + rest):
                 assert len(got) == len(whole[t]) and (got == whole[t]).all(), "rep %d frame %d mode512=%s" % (rep, t, mode512)
+
+
+def test_pack_unpack_frames(torch, hip):
+    """agmv_hip_pack_frames_dev / agmv_hip_unpack_frames_dev (the message of the GOP-sharded encoder's final gather): ragged
+    sizes with empty frames, every alignment of the message offsets, rows longer than one chunk; against plain slicing"""
+    rng = np.random.default_rng(11)
+    for n, stride, big in ((1, 256, 0), (7, 512, 0), (301, 1280, 0), (40, 70400, 60000)):
+        slab = torch.from_numpy(rng.integers(0, 256, (n, stride), dtype=np.uint8)).cuda()
+        sz = rng.integers(0, min(stride, 700) + 1, n)
+        sz[rng.integers(0, n, max(1, n // 5))] = 0
+        if big:
+            sz[::3] = rng.integers(big - 5, big + 5, len(sz[::3]))
+        sizes = torch.from_numpy(sz.astype(np.int32)).cuda()
+        packed, offs = hip.pack_frames_dev(slab, sizes)
+        exp = torch.cat([slab[f, :int(sz[f])] for f in range(n)]) if sz.sum() else slab.new_empty(0)
+        assert torch.equal(packed, exp)
+        assert offs.cpu().tolist() == [0] + np.cumsum(sz).tolist()
+        back = hip.unpack_frames_dev(packed, sizes, stride)
+        keep = torch.arange(stride, device="cuda")[None, :] < sizes[:, None]
+        assert torch.equal(back, slab * keep)

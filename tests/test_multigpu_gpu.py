@@ -37,7 +37,9 @@ def _worker(rank, world, port, q, kind):
     d = torch.from_numpy(frames[lo:hi].view(np.int32)).cuda()
     out, sizes = hip.encode_dev(d, hi - lo, W, H, first_frame_count=lo)
     hip.check()
-    got = shard.gather_bitstreams(dist, sizes, shard.pack_frames(out, sizes), dst=0)      # DEVICE tensors, as bench.py passes them to RCCL
+    packed = shard.pack_frames(out, sizes, hip=hip)            # agmv_hip_pack_frames_dev, as in bench.py
+    assert torch.equal(packed, shard.pack_frames(out, sizes))
+    got = shard.gather_bitstreams(dist, sizes, packed, dst=0)  # DEVICE tensors, as bench.py passes them to RCCL
     assert rank != 0 or all(s_.is_cuda and p_.is_cuda for s_, p_ in got)
     ok = True
     bits = None
