@@ -561,6 +561,73 @@ def test_fuzz_parser_random_bytes(torch, hip, monkeypatch, seed):
             assert (got[f] == exp[f]).all(), "pixels frame %d bpos %d (%dx%d mode512=%s)" % (f, bpos[f], W, H, mode512)
 
 
+@pytest.mark.parametrize("seed", range(int(os.environ.get("AGMV_FUZZ_SEEDS", "6"))))
+def test_fuzz_parser_block_sequences(torch, hip, monkeypatch, seed):
+    """the fast parser's STRETCH steps (a run of COPY / two- and three-byte FILL blocks taken at once) against the one-lane
+    serial walk on streams that are sequences of blocks -- long clean runs, FILL bodies that hold flag values (0x4E 0x4E,
+    0x4E 0x5E ...), escape codes, NORMAL blocks with flag-valued and escaped codes, stray bytes between blocks -- cut at
+    every kind of bpos; both parser forms, both decode forms."""
+    rng = np.random.default_rng(9000 + seed)
+    W, H = 4 * int(rng.integers(8, 120)), 4 * int(rng.integers(8, 80))
+    nblk = W * H // 16
+    n = int(rng.integers(2, 7))
+    mode512 = bool(rng.integers(0, 2)) if seed else True
+    stride = hip.max_usize(W, H)
+    p_copy, p_fill, p_norm, p_junk = rng.dirichlet([4, 4, 1, 0.3]) if seed % 3 else (0.45, 0.5, 0.04, 0.01)
+    spicy = np.array([0x4E, 0x5E, 0x2F, 0x7F, 0xFF, 0x7E, 0x00], np.uint8)
+
+    def code():
+        c = int(rng.choice(spicy)) if rng.random() < 0.25 else int(rng.integers(0, 256))
+        if mode512 and (c & 0x7F) == 127:
+            return [c, int(rng.integers(127, 256))]
+        return [c]
+
+    bits = np.zeros((n, stride), np.uint8)
+    bpos = np.zeros(n, np.int32)
+    for f in range(n):
+        buf = []
+        blocks = int(nblk * rng.choice([0.3, 1.0, 1.0, 1.2]))
+        for _ in range(blocks):
+            r = rng.random()
+            if r < p_copy:
+                buf.append(0x5E)
+            elif r < p_copy + p_fill:
+                buf.append(0x4E); buf += code()
+            elif r < p_copy + p_fill + p_norm:
+                buf.append(0x2F)
+                for _ in range(16):
+                    buf += code()
+            else:
+                buf += [int(x) for x in rng.integers(0, 256, int(rng.integers(1, 4)))]
+            if len(buf) > stride - 64:
+                break
+        buf = np.array(buf[:stride - 32], np.uint8)
+        bits[f, :len(buf)] = buf
+        bpos[f] = int(rng.choice([len(buf), len(buf), max(0, len(buf) - int(rng.integers(0, 70))), int(rng.integers(0, len(buf) + 1))]))
+        bits[f, len(buf):len(buf) + 16] = rng.integers(0, 256, 16)          # stale bytes behind the stream
+    p0, p1 = S.random_palettes(seed)
+    hip.set_palette(p0, p1, mode512)
+    dbits, dbpos = torch.from_numpy(bits).cuda(), torch.from_numpy(bpos).cuda()
+    monkeypatch.setenv("AGMV_HIP_PARSE", "serial")
+    o_ser, n_ser = hip.parse_dev(dbits, dbpos, n, W, H)
+    torch.cuda.synchronize()
+    ne = n_ser.cpu().numpy()
+    for how in (None, "robust"):
+        if how:
+            monkeypatch.setenv("AGMV_HIP_PARSE", how)
+        else:
+            monkeypatch.delenv("AGMV_HIP_PARSE")
+        o_par, n_par = hip.parse_dev(dbits, dbpos, n, W, H)
+        torch.cuda.synchronize()
+        assert torch.equal(n_ser, n_par), (how, ne, n_par.cpu().numpy(), bpos)
+        for f in range(n):
+            assert torch.equal(o_ser[f, :ne[f]], o_par[f, :ne[f]]), "%s frame %d bpos %d nentered %d (%dx%d mode512=%s)" % (how, f, bpos[f], ne[f], W, H, mode512)
+    monkeypatch.delenv("AGMV_HIP_PARSE", raising=False)
+    a = hip.decode_dev(dbits, dbpos, o_ser, n_ser, n, W, H, 0)
+    torch.cuda.synchronize()
+    same_without_offsets(torch, hip, dbits, dbpos, n, W, H, 0, None, None, a, n_ser)
+
+
 @pytest.mark.parametrize("mode512", [True, False])
 def test_parser_proof_repair_and_fallback(torch, hip, monkeypatch, mode512):
     """The speculative parser on streams built to defeat the speculation.  "4E 4E 4E 4E ..." is a run of two-byte FILLs
