@@ -1,7 +1,7 @@
 """k_encode timing of several library builds in ONE process (256 x 1080p resident clips, median of 7).
 
 usage: probe_multi.py KIND[,KIND...] NAME...    NAME -> tools/variants/libagmv_hip_NAME.so ("BASE" = the product build)
-kinds: synth | noise3 | noise | flat | hgrad (see probe_enc.py)"""
+kinds: synth | noise3 | noise | flat | hgrad (see probe_enc.py) | synthpP (the first P frames of synth repeated)"""
 import os, sys
 import numpy as np, torch
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -29,6 +29,8 @@ for k in kinds:
     elif k == "hgrad":
         x = (torch.arange(W, device="cuda", dtype=torch.int32) // 16) & 0xff
         clips[k] = (x | (x << 8) | (x << 16)).view(1, 1, W).expand(T, H, W).contiguous()
+    elif k.startswith("synthp"):                               # the synthetic clip with period P frames (synthp8: two GOPs repeated): same motion
+        P = int(k[6:]); clips[k] = synth[:P].repeat(T // P, 1, 1).contiguous()      # inside a GOP, but the clip's colour set is that of P frames
     elif k == "noise3":
         r = lambda: torch.randint(0, 8, (T, H, W), dtype=torch.int32, device="cuda", generator=g)
         clips[k] = synth ^ r() ^ (r() << 8) ^ (r() << 16)
