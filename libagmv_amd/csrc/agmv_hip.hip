@@ -1664,9 +1664,25 @@ __global__ __launch_bounds__(64) void k_fp_tiles(FpArgs A)
 		const uint32_t first = incl - n;
 		uint32_t end = kb + tot;
 		if (end > A.nblk) end = A.nblk;
-		for (uint32_t m = (kb + DEC_T - 1) / DEC_T; m * DEC_T < end; m++) {     // (uniform) tiles whose first block is entered in this region
-			const uint32_t target = m * DEC_T - kb;
-			if (target >= first && target < first + n) tx[m] = r * FRB + (uint32_t)lane * FC + select64(V, target - first);
+		// tiles whose first block is entered in this region: m0 .. m0 + nt - 1 (uniform).  The kernel is bound by VALU issue, so
+		// the bit select runs ONCE, on lane j for tile m0 + j: per tile only the piece that holds its first block is found (the
+		// pieces' inclusive counts are monotone: it is the number of pieces that end at or before the target) and its bitmap
+		// word and rank are handed to lane j.
+		const uint32_t m0 = (kb + DEC_T - 1) / DEC_T;
+		uint32_t nt = end > m0 * DEC_T ? (end - m0 * DEC_T + DEC_T - 1) / DEC_T : 0u;
+		for (uint32_t j0 = 0; j0 < nt; j0 += 64) {                 // (more than 64 tiles per region: never with DEC_T = 256)
+			const uint32_t cnt = min(nt - j0, 64u);
+			uint32_t xlo = 0, xhi = 0, xr = 0, xo = 0;
+			for (uint32_t j = 0; j < cnt; j++) {
+				const uint32_t target = (m0 + j0 + j) * DEC_T - kb;
+				const int ol = (int)__popcll(__ballot(incl <= target));     // < 64: target < tot
+				const uint32_t vl = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)V, ol), vh = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(V >> 32), ol);
+				const uint32_t fo = (uint32_t)__builtin_amdgcn_readlane((int)first, ol);
+				const bool me = (uint32_t)lane == j;
+				xlo = me ? vl : xlo; xhi = me ? vh : xhi; xr = me ? target - fo : xr; xo = me ? (uint32_t)ol : xo;
+			}
+			if ((uint32_t)lane < cnt)
+				tx[m0 + j0 + lane] = r * FRB + xo * FC + select64((unsigned long long)xhi << 32 | xlo, xr);
 		}
 	}
 	}
