@@ -48,6 +48,13 @@ def load_library(path=None):
     if not os.path.exists(p):
         raise HipUnavailable("%s is missing: run `python -m libagmv_amd.build` (or "
                              "__graft_entry__.build()); the AGMV hot path has no CPU fallback" % p)
+    # PyTorch ships its own copies of the HIP / HSA runtimes.  This module works on torch device tensors, so torch's runtime is
+    # loaded FIRST: with libagmv_hip.so (linked against /opt/rocm) in the process before `import torch`, the two resolve against
+    # each other's libraries and hipGetDeviceCount then reports no device (seen with build() followed by smoke() in one process).
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     try:
         L = C.CDLL(p)
     except OSError as e:
