@@ -283,16 +283,34 @@ def main():
     achieved = alg_bytes / (enc_ms * 1e-3) / 1e9
 
     # final gather of the job's bitstreams to rank 0 (the only data collective; outside the timed region)
-    gather_ms = None
+    gather_ms, gather_err, gather_hung = None, None, False
     if dist is not None:
         torch.cuda.synchronize()
-        g0 = time.perf_counter()
         from libagmv_amd import shard
-        gathered = shard.gather_bitstreams(dist, sizes, shard.pack_frames(out, sizes, hip=hip), dst=0)
-        if rank == 0:
-            assert sum(int(s.numel()) for s, _ in gathered) == (T if args.scaling == "strong" else world * n_enc)
-        torch.cuda.synchronize()
-        gather_ms = (time.perf_counter() - g0) * 1e3
+        import threading
+        box, done = {}, threading.Event()
+
+        def final_gather():
+            # outside the timed region, and on a watchdog: the RCCL send/recv path has only ever been rehearsed with gloo (no
+            # multi-GPU box in the build rounds) -- a failure or a hang here must not cost the job its line
+            try:
+                torch.cuda.set_device(local_rank)
+                g0 = time.perf_counter()
+                gathered = shard.gather_bitstreams(dist, sizes, shard.pack_frames(out, sizes, hip=hip), dst=0)
+                if rank == 0:
+                    assert sum(int(s.numel()) for s, _ in gathered) == (T if args.scaling == "strong" else world * n_enc)
+                torch.cuda.synchronize()
+                box["ms"] = (time.perf_counter() - g0) * 1e3
+            except Exception as e:                             # noqa: BLE001 -- reported in the line, not hidden
+                box["err"] = "%s: %s" % (type(e).__name__, str(e)[:200])
+            finally:
+                done.set()
+
+        threading.Thread(target=final_gather, daemon=True).start()
+        if not done.wait(float(os.environ.get("AGMV_BENCH_GATHER_TIMEOUT", "120"))):
+            gather_err, gather_hung = "no completion within the watchdog's time", True
+        else:
+            gather_ms, gather_err = box.get("ms"), box.get("err")
 
     if rank == 0:
         traffic = None
@@ -333,6 +351,8 @@ def main():
         }
         if gather_ms is not None:
             res["final_gather_ms"] = round(gather_ms, 3)
+        if gather_err is not None:
+            res["final_gather_error"] = gather_err
         if world == 1 and not args.no_cpu_baseline:
             n_cpu = args.cpu_frames or (8 if npx > 500000 else 32)
             n_cpu = min(n_cpu, n_enc)
@@ -356,6 +376,9 @@ def main():
             res["secondary"] = secondary_legs(torch, local_rank, dev)
         print(json.dumps(res))
     if dist is not None:
+        if gather_hung or gather_err is not None:              # the process group is in an unknown state: leave without its teardown
+            sys.stdout.flush()
+            os._exit(0)
         dist.barrier()
         dist.destroy_process_group()
     hip.close()
