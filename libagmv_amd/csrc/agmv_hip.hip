@@ -1518,6 +1518,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 8))) void
 {
 	__shared__ uint32_t s_b[FP_LDS];
 	const int lane = threadIdx.x;
+	if (blockIdx.x == 0 && blockIdx.y == 0 && lane == 0) *A.nbad = 0;   // (k_fp_finish, the next launch, counts the frames it gives up; saves a fill launch)
 	for (uint32_t f = blockIdx.y; f < A.n_frames; f += gridDim.y) {   // (many small frames: the grid is capped, rows stride over the frames)
 		const uint32_t bpos = A.bpos[f];
 		const uint32_t nreg = min(bpos / FRB + 1u, A.maxR);    // positions 0 .. bpos can hold nodes
@@ -1536,6 +1537,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
 	const uint32_t bpos = A.bpos[f];
 	const uint32_t nreg = min(bpos / FRB + 1u, A.maxR);
 	uint4* rec = A.rec + (size_t)f * A.maxR;
+	if (A.tidx)                                                // bitmap form: the frame's tile entries start out as "not entered" (k_fp_tiles, a later launch, writes those that are)
+		for (uint32_t t = lane; t <= A.tpfd; t += 64) A.tidx[(size_t)f * (A.tpfd + 1) + t] = TIDX_NONE;
 	// the first region at or behind `start` whose entry is not the exit of the region before it is walked again with that
 	// exit forced; its own exit may have changed, so the search goes on right behind it
 	int budget = FP_REPAIRS;
@@ -2921,9 +2924,8 @@ static int parse_launch(agmv_hip_ctx* c, const uint8_t* d_bits, size_t stride, c
 		if ((size_t)gx * gy > 131072u) gy = 131072u / gx;
 	}
 	const dim3 grid(gx, gy);
-	if (bitmap) CK(hipMemsetAsync(A.tidx, 0xFF, (size_t)n_frames * (tpfd + 1) * 4, s));   // TIDX_NONE
-	CK(hipMemsetAsync(A.nbad, 0, 4, s));
 	if (robust_only) {                                         // debugging aid: every frame through the robust kernels (bitmap form)
+		if (bitmap) CK(hipMemsetAsync(A.tidx, 0xFF, (size_t)n_frames * (tpfd + 1) * 4, s));   // TIDX_NONE (otherwise k_fp_finish's job; nbad: k_fp_walk's)
 		CK(hipMemsetD32Async((hipDeviceptr_t)A.fstate, (int)FS_BAD, n_frames, s));
 		CK(hipMemsetD32Async((hipDeviceptr_t)A.nbad, (int)n_frames, 1, s));
 	} else {
