@@ -1314,6 +1314,8 @@ struct FpArgs {
 	uint32_t* nbad;             // frames given up (FS_BAD), counted by k_fp_finish
 	uint32_t* tidx;             // [n_frames][tpfd + 1] byte position at which the first block of every k_decode tile is entered (TIDX_NONE: not entered)
 	uint32_t tpfd;              // k_decode tiles per frame
+	uint32_t* dirty;            // != NULL: k_decode's repair bitmap, cleared by k_fp_tiles (the last parser launch in front of it)
+	uint32_t ndirty;
 };
 constexpr uint32_t TIDX_NONE = 0xFFFFFFFFu;
 
@@ -1653,6 +1655,8 @@ __device__ __forceinline__ uint32_t select64(unsigned long long v, uint32_t k)
 __global__ __launch_bounds__(64) void k_fp_tiles(FpArgs A)
 {
 	const int lane = threadIdx.x;
+	if (A.dirty && blockIdx.x == 0 && blockIdx.y == 0)         // (saves the fill launch in front of k_decode)
+		for (uint32_t i = lane; i < A.ndirty; i += 64) A.dirty[i] = 0;
 	for (uint32_t f = blockIdx.y; f < A.n_frames; f += gridDim.y) {
 	if (A.fstate[f] == FS_BAD) continue;                       // (cannot happen behind k_fp_recount; a frame without bitmaps has no tiles)
 	const uint32_t nreg = min(A.bpos[f] / FRB + 1u, A.maxR);
@@ -2881,7 +2885,8 @@ static int parse_launch_robust(agmv_hip_ctx* c, const uint8_t* d_bits, size_t st
 // the parser: speculative walks proven per frame (k_fp_*), the robust kernels for the frames that could not be proven.
 // AGMV_HIP_PARSE=robust runs the robust kernels alone.
 static int parse_launch(agmv_hip_ctx* c, const uint8_t* d_bits, size_t stride, const uint32_t* d_bpos, uint32_t n_frames,
-                        uint32_t nblk, uint32_t* d_offsets, uint32_t* d_nentered, size_t ws_frames, hipStream_t s, bool bitmap = false)
+                        uint32_t nblk, uint32_t* d_offsets, uint32_t* d_nentered, size_t ws_frames, hipStream_t s, bool bitmap = false,
+                        uint32_t* dirty = nullptr, uint32_t ndirty = 0)
 {
 	const char* mode = getenv("AGMV_HIP_PARSE");
 	const bool robust_only = mode && strcmp(mode, "robust") == 0;
@@ -2908,7 +2913,7 @@ static int parse_launch(agmv_hip_ctx* c, const uint8_t* d_bits, size_t stride, c
 	A.rec = (uint4*)w; A.vm = (unsigned long long*)(w + b_rec); A.kb = (uint32_t*)(w + b_rec + b_vm); A.fstate = (uint32_t*)(w + b_rec + b_vm + b_kb);
 	A.tidx = bitmap ? (uint32_t*)(w + b_rec + b_vm + b_kb + b_fs) : nullptr; A.tpfd = tpfd;
 	A.nbad = (uint32_t*)(w + b_rec + b_vm + b_kb + b_fs + b_tx);
-	A.n_frames = n_frames; A.nblk = nblk; A.maxR = (uint32_t)maxR;
+	A.n_frames = n_frames; A.nblk = nblk; A.maxR = (uint32_t)maxR; A.dirty = dirty; A.ndirty = ndirty;
 	uint32_t gx = (uint32_t)(((size_t)c->n_cu * 512 + n_frames - 1) / n_frames);
 	if (gx < 32) gx = 32;
 	if (gx > 256) gx = 256;
@@ -2999,7 +3004,8 @@ extern "C" int agmv_hip_parse_fallback_frames(agmv_hip_ctx* c, void* stream)
 // arguments of k_decode / k_fixup for a batch; grows and clears the context's bitmap of positions to repair
 static int decode_prepare(agmv_hip_ctx* c, DecArgs& A, const uint8_t* d_bits, size_t stride, const uint32_t* d_bpos,
                           const uint32_t* d_offsets, const uint32_t* d_nentered, uint32_t n_frames, uint32_t w, uint32_t h,
-                          uint32_t first_fc, uint32_t* d_out, const uint32_t* d_prev, const uint32_t* d_prev_iframe, hipStream_t s)
+                          uint32_t first_fc, uint32_t* d_out, const uint32_t* d_prev, const uint32_t* d_prev_iframe, hipStream_t s,
+                          uint32_t* ndirty_out = nullptr /* != NULL: the caller has the bitmap cleared (k_fp_tiles) */)
 {
 	if (((uintptr_t)d_out & 15u) || ((uintptr_t)d_prev & 15u) || ((uintptr_t)d_prev_iframe & 15u)) {
 		snprintf(g_err, sizeof(g_err), "agmv_hip: pixel buffers must be 16-byte aligned"); return -1;
@@ -3020,7 +3026,8 @@ static int decode_prepare(agmv_hip_ctx* c, DecArgs& A, const uint8_t* d_bits, si
 		c->dirty_cap = nwords;
 	}
 	A.dirty = c->d_dirty;
-	CK(hipMemsetAsync(c->d_dirty, 0, nwords * 4, s));
+	if (ndirty_out) *ndirty_out = (uint32_t)nwords;
+	else CK(hipMemsetAsync(c->d_dirty, 0, nwords * 4, s));
 	return 0;
 }
 
@@ -3155,9 +3162,10 @@ extern "C" int agmv_hip_decode_bitstreams_dev(agmv_hip_ctx* c, const uint8_t* d_
 		const uint32_t* prev = f0 == 0 ? d_prev : d_out + (size_t)(f0 - 1) * npx;
 		const uint32_t* previ = f0 == 0 ? d_prev_iframe : d_out + (size_t)(f0 - 4) * npx;
 		DecArgs A;
-		if (decode_prepare(c, A, d_bits + (size_t)f0 * stride, stride, d_bpos + f0, nullptr, d_nentered + f0, n, w, h, fc, d_out + (size_t)f0 * npx, prev, previ, s)) return -1;
+		uint32_t ndirty = 0;
+		if (decode_prepare(c, A, d_bits + (size_t)f0 * stride, stride, d_bpos + f0, nullptr, d_nentered + f0, n, w, h, fc, d_out + (size_t)f0 * npx, prev, previ, s, &ndirty)) return -1;
 		ev_mark(c, 2, s);
-		if (parse_launch(c, d_bits + (size_t)f0 * stride, stride, d_bpos + f0, n, A.nblk, nullptr, d_nentered + f0, n, s, true)) return -1;
+		if (parse_launch(c, d_bits + (size_t)f0 * stride, stride, d_bpos + f0, n, A.nblk, nullptr, d_nentered + f0, n, s, true, A.dirty, ndirty)) return -1;
 		ev_mark(c, 3, s);
 		A.vm = c->fp_vm; A.kb = c->fp_kb; A.tidx = c->fp_tidx; A.maxR = c->fp_maxR;
 		ev_mark(c, 4, s);
