@@ -971,7 +971,7 @@ struct ParseArgs {
 	const uint8_t* bits;
 	unsigned long long stride;
 	const uint32_t* bpos;
-	uint32_t* cum;          // [n_frames+1] exclusive prefix of chunks per frame
+	uint32_t cpf;           // chunk rows per frame in summ / centry (the worst case: frame f's chunk c is row f * cpf + c -- no prefix over the frames, no launch for one)
 	uint16_t* summ;         // [chunk][33] exit<<10 | count   (exit X_END: chain ended in the chunk)
 	uint32_t* centry;       // [chunk] kbase<<8 | entry offset (0xff: chain never reaches the chunk)
 	uint32_t* offsets;
@@ -984,19 +984,10 @@ struct ParseArgs {
 };
 constexpr uint32_t FS_OK = 0, FS_TODO = 1, FS_BAD = 2;
 
-__global__ __launch_bounds__(64) void k_parse_prefix(ParseArgs A)
+// chunks of frame f that the robust kernels parse: ceil((bpos + 1) / PC), or none when the frame is not theirs
+__device__ __forceinline__ uint32_t parse_nch(const ParseArgs& A, uint32_t f, uint32_t bpos)
 {
-	const int lane = threadIdx.x;
-	if (A.nbad && *A.nbad == 0) return;
-	uint32_t run = 0;
-	for (uint32_t f0 = 0; f0 < A.n_frames; f0 += 64) {
-		const uint32_t f = f0 + lane;
-		const uint32_t x = (f < A.n_frames && (!A.fstate || A.fstate[f] == FS_BAD)) ? (A.bpos[f] + PC) / PC : 0u;     // ceil((bpos+1)/PC)
-		const uint32_t incl = wave_incl_scan(x, lane);
-		if (f < A.n_frames) A.cum[f] = run + incl - x;
-		run += __shfl(incl, 63, 64);
-	}
-	if (lane == 0) A.cum[A.n_frames] = run;
+	return (!A.fstate || A.fstate[f] == FS_BAD) ? (bpos + PC) / PC : 0u;
 }
 
 __device__ __forceinline__ void wave_lds_sync()
@@ -1108,7 +1099,7 @@ __global__ __launch_bounds__(64) void k_parse_chunks(ParseArgs A)
 	if (A.nbad && *A.nbad == 0) return;
 	// 2-D grid: y strides over frames, x over the chunks of a frame (no search for the frame of a chunk)
 	for (uint32_t f = blockIdx.y; f < A.n_frames; f += gridDim.y) {
-	const uint32_t g0 = A.cum[f], nch = A.cum[f + 1] - g0, bpos = A.bpos[f];
+	const uint32_t bpos = A.bpos[f], g0 = f * A.cpf, nch = parse_nch(A, f, bpos);
 	const uint8_t* fbits = A.bits + (size_t)f * A.stride;
 	uint32_t nxt[PCD];
 	if (blockIdx.x < nch) load_chunk(nxt, fbits, (uint32_t)A.stride, blockIdx.x * PC, lane);
@@ -1164,7 +1155,7 @@ __global__ __launch_bounds__(64) void k_parse_stitch(ParseArgs A)
 	const int lane = threadIdx.x;
 	if (A.nbad && *A.nbad == 0) return;
 	for (uint32_t f = blockIdx.x; f < A.n_frames; f += gridDim.x) {
-	const uint32_t c0 = A.cum[f], nch = A.cum[f + 1] - c0;     // nch >= 1 for a frame that is parsed here
+	const uint32_t c0 = f * A.cpf, nch = parse_nch(A, f, A.bpos[f]);     // nch >= 1 for a frame that is parsed here
 	if (nch == 0) continue;
 	const uint16_t* rows = A.summ + (size_t)c0 * 33 + (lane < 33 ? lane : 0);
 	uint32_t o = 0, kb = 0;
@@ -1203,7 +1194,7 @@ __global__ __launch_bounds__(64) void k_parse_emit(ParseArgs A)
 	const int lane = threadIdx.x;
 	if (A.nbad && *A.nbad == 0) return;
 	for (uint32_t f = blockIdx.y; f < A.n_frames; f += gridDim.y) {
-	const uint32_t g0 = A.cum[f], nch = A.cum[f + 1] - g0, bpos = A.bpos[f];
+	const uint32_t bpos = A.bpos[f], g0 = f * A.cpf, nch = parse_nch(A, f, bpos);
 	const uint8_t* fbits = A.bits + (size_t)f * A.stride;
 	uint32_t* off = A.offsets + (size_t)f * A.nblk;
 	uint32_t nxt[PCD], ce_n = 0;
@@ -1658,12 +1649,24 @@ __global__ __launch_bounds__(64) void k_fp_tiles(FpArgs A)
 	if (A.dirty && blockIdx.x == 0 && blockIdx.y == 0)         // (saves the fill launch in front of k_decode)
 		for (uint32_t i = lane; i < A.ndirty; i += 64) A.dirty[i] = 0;
 	for (uint32_t f = blockIdx.y; f < A.n_frames; f += gridDim.y) {
-	if (A.fstate[f] == FS_BAD) continue;                       // (cannot happen behind k_fp_recount; a frame without bitmaps has no tiles)
+	const bool fell_back = A.fstate[f] == FS_BAD;              // its entry bits come from the robust kernels (k_parse_emit), nobody has numbered its blocks yet
 	const uint32_t nreg = min(A.bpos[f] / FRB + 1u, A.maxR);
 	uint32_t* tx = A.tidx + (size_t)f * (A.tpfd + 1);
 	for (uint32_t r = blockIdx.x; r < nreg; r += gridDim.x) {
-		const uint32_t kb = A.kb[(size_t)f * A.maxR + r];
-		if (kb >= A.nblk) break;                                // (uniform) blocks beyond the frame are never entered
+		uint32_t kb;
+		if (fell_back) {
+			// first block number of the region = entries in the regions before it: counted here, by the region's own wave (the
+			// exception path: a launch of its own for this cost 5 us on every decode call that had nothing to count)
+			const unsigned long long* v = A.vm + (size_t)f * A.maxR * FOWN;
+			uint32_t n = 0;
+			for (uint32_t i = lane; i < r * FOWN; i += 64) n += (uint32_t)__popcll(v[i]);
+			kb = wave_sum(n);
+			if (lane == 0) A.kb[(size_t)f * A.maxR + r] = kb;
+		} else kb = A.kb[(size_t)f * A.maxR + r];
+		if (kb >= A.nblk) {                                     // (uniform) blocks beyond the frame are never entered
+			if (fell_back) continue;                            // (its later regions still get their number: bm_offset_of searches kb[] of the whole frame)
+			break;
+		}
 		const unsigned long long V = lane < FOWN ? A.vm[((size_t)f * A.maxR + r) * FOWN + lane] : 0ull;
 		const uint32_t n = (uint32_t)__popcll(V);
 		const uint32_t incl = wave_incl_scan(n, lane);
@@ -1692,32 +1695,6 @@ __global__ __launch_bounds__(64) void k_fp_tiles(FpArgs A)
 				tx[m0 + j0 + lane] = r * FRB + xo * FC + select64((unsigned long long)xhi << 32 | xlo, xr);
 		}
 	}
-	}
-}
-
-// Frames the fast parser gave up on, after the robust kernels have set their entry bits (k_parse_emit, bitmap form): count
-// the entries per region and number the blocks, as k_fp_finish does for a proven frame.
-constexpr uint32_t FS_FIXED = 3;
-__global__ __launch_bounds__(64) void k_fp_recount(FpArgs A)
-{
-	const int lane = threadIdx.x;
-	if (*A.nbad == 0) return;
-	for (uint32_t f = blockIdx.x; f < A.n_frames; f += gridDim.x) {
-		if (A.fstate[f] != FS_BAD) continue;
-		const uint32_t nreg = min(A.bpos[f] / FRB + 1u, A.maxR);
-		uint32_t run = 0;
-		for (uint32_t r0 = 0; r0 < nreg; r0 += 64) {
-			const uint32_t r = r0 + lane;
-			uint32_t n = 0;
-			if (r < nreg) {
-				const unsigned long long* v = A.vm + ((size_t)f * A.maxR + r) * FOWN;
-				for (int k = 0; k < FOWN; k++) n += (uint32_t)__popcll(v[k]);
-			}
-			const uint32_t incl = wave_incl_scan(n, lane);
-			if (r < nreg) A.kb[(size_t)f * A.maxR + r] = run + incl - n;
-			run += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-		}
-		if (lane == 0) A.fstate[f] = FS_FIXED;
 	}
 }
 
@@ -2844,7 +2821,8 @@ static int parse_launch_robust(agmv_hip_ctx* c, const uint8_t* d_bits, size_t st
                                unsigned long long* vm = nullptr, uint32_t maxR = 0, const uint32_t* nbad = nullptr)
 {
 	const size_t cpf = (stride + PC) / PC, maxchunks = cpf * ws_frames;
-	const size_t need = ws_frames + 1 + maxchunks + (maxchunks * 33 + 1) / 2 + 16;   // dwords: cum | centry | summ (u16)
+	if (maxchunks >> 32) { snprintf(g_err, sizeof(g_err), "agmv_hip: parser batch too large (%zu chunk rows)", maxchunks); return -1; }
+	const size_t need = maxchunks + (maxchunks * 33 + 1) / 2 + 16;   // dwords: centry | summ (u16)
 	if (need > c->parse_ws_cap) {
 		if (c->d_parse_ws) CK(hipFree(c->d_parse_ws));
 		c->d_parse_ws = nullptr; c->parse_ws_cap = 0;
@@ -2854,7 +2832,7 @@ static int parse_launch_robust(agmv_hip_ctx* c, const uint8_t* d_bits, size_t st
 	ParseArgs A;
 	memset(&A, 0, sizeof(A));
 	A.bits = d_bits; A.stride = stride; A.bpos = d_bpos; A.offsets = d_offsets; A.nentered = d_nentered;
-	A.cum = c->d_parse_ws; A.centry = A.cum + ws_frames + 1; A.summ = (uint16_t*)(A.centry + maxchunks);
+	A.cpf = (uint32_t)cpf; A.centry = c->d_parse_ws; A.summ = (uint16_t*)(A.centry + maxchunks);
 	A.n_frames = n_frames; A.nblk = nblk; A.fstate = fstate; A.vm = vm; A.maxR = maxR; A.nbad = nbad;
 	// the exception path (fstate): a few rows of workgroups stride over the frames and leave those that are not FS_BAD at
 	// once -- with one row per frame the three gated launches cost 0.03 ms per 1024 frames for zero frames to parse
@@ -2869,8 +2847,6 @@ static int parse_launch_robust(agmv_hip_ctx* c, const uint8_t* d_bits, size_t st
 	if (gx > cpf) gx = (uint32_t)cpf;
 	if (gx < 1) gx = 1;
 	const dim3 grid(gx, gy.y);
-	hipLaunchKernelGGL(k_parse_prefix, dim3(1), dim3(64), 0, s, A);
-	CK(hipGetLastError());
 	if (c->mode512) hipLaunchKernelGGL(k_parse_chunks<true>, grid, dim3(64), 0, s, A);
 	else            hipLaunchKernelGGL(k_parse_chunks<false>, grid, dim3(64), 0, s, A);
 	CK(hipGetLastError());
@@ -2952,10 +2928,8 @@ static int parse_launch(agmv_hip_ctx* c, const uint8_t* d_bits, size_t stride, c
 		return parse_launch_robust(c, d_bits, stride, d_bpos, n_frames, nblk, d_offsets, d_nentered, ws_frames, A.fstate, s, nullptr, 0, A.nbad);
 	}
 	// bitmap form: the frames that could not be proven get their entry BITS from the robust kernels, are counted and
-	// numbered like the proven ones (k_fp_recount), then every frame's tile entries are looked up
+	// numbered by k_fp_tiles, which then looks up every frame's tile entries
 	if (parse_launch_robust(c, d_bits, stride, d_bpos, n_frames, nblk, nullptr, d_nentered, ws_frames, A.fstate, s, A.vm, A.maxR, A.nbad)) return -1;
-	hipLaunchKernelGGL(k_fp_recount, dim3(n_frames < 1024u ? n_frames : 1024u), dim3(64), 0, s, A);
-	CK(hipGetLastError());
 	uint32_t gt = gx / 2 ? gx / 2 : 1;
 	if (getenv("AGMV_TILES_GX")) gt = (uint32_t)atoi(getenv("AGMV_TILES_GX"));   // tuning aid
 	if (gt < 1) gt = 1;
